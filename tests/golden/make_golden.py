@@ -1,0 +1,188 @@
+"""tests/golden/make_golden.py -- mints tests/golden/*.npz by running the REAL reference code on CPU.
+
+Run in the build container only (needs /root/reference):   python tests/golden/make_golden.py
+The reference's BufferX.forward (inference branch, models/BUFFERX.py:257-467) is executed unmodified
+through tests/golden/ref_harness.py (third-party CUDA ops stubbed in numpy).  Inputs are functions of
+seeds only (bufferx_amd.synth / bufferx_amd.weights.synthetic_state_dict), so the fixtures store seeds,
+config overrides and the reference's intermediate + final outputs -- not the clouds or the weights.
+"""
+import os
+import sys
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+import ref_harness as rh  # noqa: E402
+import bufferx_amd  # noqa: E402
+
+CASES = {
+    # name: (dataset cfg, synth kind, n_target, seed, overrides)
+    "indoor_small": ("3DMatch", "indoor", 3500, 11,
+                     dict(num_fps=96, num_points_per_patch=96, num_scales=2, search_radius_thresholds=[5, 2],
+                          num_points_radius_estimate=256, iter_n=4000)),
+    "indoor_success": ("3DMatch", "indoor_identical", 5000, 3,
+                       dict(num_fps=256, num_points_per_patch=128, num_scales=2, search_radius_thresholds=[2, 1],
+                            num_points_radius_estimate=256, iter_n=4000)),
+    "indoor_early": ("3DMatch", "indoor_identical", 4000, 4,
+                     dict(num_fps=192, num_points_per_patch=96, num_scales=2, search_radius_thresholds=[2, 1],
+                          num_points_radius_estimate=192, iter_n=4000, enable_early_exit=True,
+                          early_exit_min_inliers=4)),
+    "outdoor_small": ("KITTI", "outdoor", 0, 5,
+                      dict(num_fps=80, num_points_per_patch=64, num_scales=1, search_radius_thresholds=[2],
+                           num_points_radius_estimate=200, iter_n=1200)),
+}
+
+
+def apply_overrides(cfg, ov):
+    for k, v in ov.items():
+        if k in ("iter_n", "enable_early_exit", "early_exit_min_inliers"):
+            cfg.match[k] = v
+        else:
+            cfg.patch[k] = v
+    return cfg
+
+
+def case_inputs(name):
+    ds, kind, n, seed, ov = CASES[name]
+    if kind == "indoor":
+        pair = bufferx_amd.synth.make_pair(seed, "indoor", n_target=n)
+    elif kind == "indoor_identical":
+        pair = bufferx_amd.synth.make_pair(seed, "indoor", n_target=n, identical=True)
+    else:
+        pair = bufferx_amd.synth.make_pair(seed, "outdoor", voxel=0.6)
+    return ds, pair, seed, ov
+
+
+def run_reference(name):
+    ns = rh.load_reference()
+    ds, pair, seed, ov = case_inputs(name)
+    cfg = ns.CFG.make_cfg(ds, "/tmp")
+    cfg.stage = "test"
+    apply_overrides(cfg, ov)
+    model = ns.BX.BufferX(cfg)
+    sd = bufferx_amd.weights.synthetic_state_dict(0)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model.eval()
+    cap = {}
+    src, tgt = pair["src"], pair["tgt"]
+    S = cfg.patch.num_scales
+    for i in range(S):
+        rh.PERM_QUEUE.append(rh.make_perm(len(src), seed, 2 * i))
+        rh.PERM_QUEUE.append(rh.make_perm(len(tgt), seed, 2 * i + 1))
+    rh.RANSAC_STATE.update(seed=seed, calls=0, log=[])
+
+    # ---- capture hooks (wrap, never modify, the reference functions)
+    desc_calls = []
+    orig_desc = model.Desc.forward
+
+    def desc_fwd(*a, **k):
+        out = orig_desc(*a, **k)
+        desc_calls.append({kk: vv.detach().numpy().copy() for kk, vv in out.items() if kk in ("desc", "equi", "R", "patches")})
+        return out
+
+    model.Desc.forward = desc_fwd
+    radii = []
+    orig_rad = ns.BX.density_aware_radius_estimation
+
+    def rad(*a, **k):
+        r = orig_rad(*a, **k)
+        radii.append(r[0])
+        return r
+
+    ns.BX.density_aware_radius_estimation = rad
+    mm = []
+    orig_mm = model.mutual_matching
+
+    def mutual(a, b):
+        s, t = orig_mm(a, b)
+        mm.append((s.numpy().copy(), t.numpy().copy()))
+        return s, t
+
+    model.mutual_matching = mutual
+    inds = []
+    orig_pose = model.Pose.forward
+
+    def pose_fwd(a, b):
+        r = orig_pose(a, b)
+        inds.append(r.detach().numpy().copy())
+        return r
+
+    model.Pose.forward = pose_fwd
+    est = []
+    orig_est = model.pose_estimator.estimate_pose
+
+    def est_pose(s, t, ind):
+        r = orig_est(s, t, ind)
+        est.append((np.asarray(ind).copy(), np.asarray(r[0]).copy(), int(r[1])))
+        return r
+
+    model.pose_estimator.estimate_pose = est_pose
+    with torch.no_grad():
+        out = model({"src_fds_pcd": torch.from_numpy(src), "tgt_fds_pcd": torch.from_numpy(tgt),
+                     "is_aligned_to_global_z": pair["aligned_z"]})
+    ns.BX.density_aware_radius_estimation = orig_rad
+    pose, times, num_inliers, num_mutual, num_inlier_ind, scales_used = out
+    cap["pose"] = np.asarray(pose, np.float64)
+    cap["num_inliers"] = num_inliers
+    cap["num_mutual"] = num_mutual
+    cap["num_inlier_ind"] = num_inlier_ind
+    cap["scales_used"] = scales_used
+    cap["des_r"] = np.array(radii, np.float64)
+    for j, d in enumerate(desc_calls):
+        i, c = divmod(j, 2)
+        tag = f"s{i}_{'src' if c == 0 else 'tgt'}_"
+        cap[tag + "desc"] = d["desc"]
+        cap[tag + "R"] = d["R"]
+        # keep fixtures small: a strided sample of the equivariant maps and the normalised patches
+        cap[tag + "equi_sub"] = d["equi"][::16]
+        cap[tag + "patches_sub"] = d["patches"][::16]
+    for i, (s, t) in enumerate(mm):
+        cap[f"s{i}_s_mids"], cap[f"s{i}_t_mids"] = s.astype(np.int32), t.astype(np.int32)
+    for i, v in enumerate(inds):
+        cap[f"s{i}_ind"] = v
+    for i, (ind, T, n) in enumerate(est):
+        cap[f"est{i}_inlier_ind"] = ind.astype(np.int32)
+        cap[f"est{i}_T"] = T
+        cap[f"est{i}_n"] = n
+    cap["ransac_log"] = np.array(rh.RANSAC_STATE["log"], np.int64)
+    cap["T_gt"] = pair["T_gt"]
+    cap["n_src"], cap["n_tgt"] = len(src), len(tgt)
+    cap["src_head"], cap["tgt_head"] = src[:8], tgt[:8]   # guards the synthetic generator against drift
+    return cap
+
+
+def helper_vectors():
+    """Known-answer vectors of the reference's pure helpers."""
+    ns = rh.load_reference()
+    CM = ns.CM
+    out = {}
+    out["voxel_centres"] = np.asarray(CM.get_voxel_coordinate(1, 3, 20, 7), np.float64).reshape(-1, 3).astype(np.float32)
+    R = np.zeros([20, 3, 3])
+    for i in range(20):
+        R[i] = CM.angles2rotation_matrix(-1 * i * np.array([0, 0, 2 * np.pi / 20]))
+    out["inv_rot"] = R.astype(np.float32)
+    torch.manual_seed(0)
+    P = torch.rand(20000, 3) * 4
+    out["radius_kat"] = np.array([ns.BX.density_aware_radius_estimation(P, P[:2000][None], P[:100], P[:100][None], thresholds=[t])[0]
+                                  for t in (5, 2, 0.5)])
+    out["radius_kat_pts"] = P[::50].numpy()
+    z = torch.nn.functional.normalize(torch.randn(64, 3), dim=1)
+    out["rods_in"] = z.numpy()
+    out["rods_out"] = CM.RodsRotatFormula(z, torch.FloatTensor([0, 0, 1]).expand_as(z)).numpy()
+    d = torch.randn(16, 40, 3)
+    ref = torch.randn(16, 3)
+    out["calz_in"], out["calz_ref"] = d.numpy(), ref.numpy()
+    out["calz_out"] = CM.cal_Z_axis(d, ref_point=ref).numpy()
+    return out
+
+
+if __name__ == "__main__":
+    np.savez_compressed(os.path.join(HERE, "helpers.npz"), **helper_vectors())
+    for name in CASES:
+        cap = run_reference(name)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **cap)
+        print(name, "pose err (deg, m):", bufferx_amd.synth.pose_error(cap["pose"], cap["T_gt"]),
+              "inliers", cap["num_inliers"], "mutual", cap["num_mutual"], "des_r", cap["des_r"],
+              "ransac", cap["ransac_log"].tolist())
