@@ -1,0 +1,546 @@
+// bx_api.hip -- C-ABI of libbufferx_hip.so (include/bufferx.h): context, weights, stage entry points and
+// the whole-pair pipeline (reference BufferX.forward inference branch, models/BUFFERX.py:257-467).
+#include "bx_common.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <vector>
+
+static thread_local char g_err[1024] = "";
+void bx_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+
+struct Carver {
+    char* base;
+    size_t off;
+    template <typename T>
+    T* take(size_t n)
+    {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+void carve(bx_ctx* c, char* base, size_t* total)
+{
+    const size_t K = (size_t)c->p.num_fps, P = (size_t)c->p.num_points_per_patch, S = (size_t)c->p.num_scales;
+    const size_t NK = (size_t)c->p.num_points_radius_estimate;
+    const size_t KM = K > NK ? K : NK;
+    const size_t NMAX = (size_t)c->p.max_points;
+    const size_t SK = S * K;
+    Carver cv{base, 0};
+    const size_t act = K * 2 * 972 * 16;  // largest map: CostNet layer-0 output; Desc 128-channel maps are K*8*140*16
+    c->act0 = cv.take<float>(act);
+    c->act1 = cv.take<float>(act);
+    c->patches = cv.take<float>(K * P * 3);
+    c->feat = cv.take<float>(K * BX_RAD * BX_EA * 16);
+    c->pts_perm = cv.take<float>(NMAX * 3);
+    for (int i = 0; i < 2; ++i) {
+        c->fps_idx[i] = cv.take<int32_t>(KM);
+        c->kpts[i] = cv.take<float>(KM * 3);
+        c->kpts_r[i] = c->kpts[i];
+        c->desc_out[i] = cv.take<float>(K * 32);
+        c->equi[i] = cv.take<float>(K * BX_EA * 32);
+        c->Rpatch[i] = cv.take<float>(K * 9);
+        c->nn_key[i] = cv.take<unsigned long long>(K);
+    }
+    c->s_mids = cv.take<int32_t>(K);
+    c->t_mids = cv.take<int32_t>(K);
+    c->ind = cv.take<float>(K);
+    c->R_cat = cv.take<float>(SK * 9);
+    c->t_cat = cv.take<float>(SK * 3);
+    c->ss_cat = cv.take<float>(SK * 3);
+    c->tt_cat = cv.take<float>(SK * 3);
+    c->cons_cnt = cv.take<int32_t>(SK);
+    c->cons_thr = cv.take<float>(SK);
+    c->inlier_ind = cv.take<int32_t>(SK);
+    c->rad_hist = cv.take<unsigned long long>(8200);
+    c->fps_dist = nullptr;
+    c->fps_slots = cv.take<unsigned long long>(2 * 2 * 16 * 5);
+    c->ransac_inl = cv.take<int32_t>(BX_RANSAC_BATCH);
+    c->ransac_err = cv.take<double>(BX_RANSAC_BATCH);
+    c->ransac_T = cv.take<double>((size_t)BX_RANSAC_BATCH * 12);
+    c->refine_ws = cv.take<float>(SK * 2);
+    c->refine_sel = cv.take<int32_t>(SK);
+    c->sub_pts = cv.take<float>(NMAX > 200000 ? (size_t)200000 * 3 : 16);
+    c->state = cv.take<PairState>(1);
+    c->result_dev = cv.take<bx_result>(1);
+    c->err_flag = cv.take<int32_t>(4);
+    *total = (cv.off + 255) & ~(size_t)255;
+}
+
+// host restatement of get_voxel_coordinate / var_to_invar tables (reference utils/common.py:248-262, 390-405,
+// 422-428, 483-493, 117-128): binary64 libm like numpy, then rounded to fp32 like torch.FloatTensor.
+void voxel_tables(std::vector<float>& cen, std::vector<float>& rot)
+{
+    const double PI = 3.14159265358979323846;
+    cen.resize((size_t)BX_VOX * 3);
+    rot.resize((size_t)BX_AZI * 4);
+    for (int s = 0; s < BX_RAD; ++s) {
+        double scale = (double)s / (double)BX_RAD + 1.0 / (double)(2 * BX_RAD);
+        for (int e = 0; e < BX_ELE; ++e) {
+            double beta = (double)e * (PI / (double)BX_ELE) + PI / (double)BX_ELE / 2.0;
+            for (int a = 0; a < BX_AZI; ++a) {
+                double alpha = (double)a * (2.0 * PI / (double)BX_AZI) + PI / (double)BX_AZI;
+                double x = std::sin(beta) * std::cos(alpha), y = std::sin(beta) * std::sin(alpha), z = std::cos(beta);
+                size_t o = ((size_t)(s * BX_ELE + e) * BX_AZI + a) * 3;
+                cen[o] = (float)(scale * x); cen[o + 1] = (float)(scale * y); cen[o + 2] = (float)(scale * z);
+            }
+        }
+    }
+    for (int a = 0; a < BX_AZI; ++a) {
+        double ang = -1.0 * (double)a * (2.0 * PI / (double)BX_AZI);
+        rot[a * 4 + 0] = (float)std::cos(ang);
+        rot[a * 4 + 1] = (float)(-std::sin(ang));
+        rot[a * 4 + 2] = (float)std::sin(ang);
+        rot[a * 4 + 3] = (float)std::cos(ang);
+    }
+}
+
+std::vector<int32_t> cyl_taps()
+{
+    std::vector<int32_t> t((size_t)9 * BX_EA, -1);
+    for (int kh = 0; kh < 3; ++kh)
+        for (int kw = 0; kw < 3; ++kw)
+            for (int h = 0; h < BX_ELE; ++h) {
+                int hh = h + kh - 1;
+                if (hh < 0 || hh >= BX_ELE) continue;
+                for (int w = 0; w < BX_AZI; ++w)
+                    t[(size_t)(kh * 3 + kw) * BX_EA + h * BX_AZI + w] = hh * BX_AZI + (w + kw - 1 + BX_AZI) % BX_AZI;
+            }
+    return t;
+}
+
+std::vector<int32_t> valid_taps(const int d[3], const int k[3], int o[3])
+{
+    for (int i = 0; i < 3; ++i) o[i] = d[i] - k[i] + 1;
+    std::vector<int32_t> t((size_t)k[0] * k[1] * k[2] * o[0] * o[1] * o[2]);
+    const int po = o[0] * o[1] * o[2];
+    for (int a = 0; a < k[0]; ++a)
+        for (int b = 0; b < k[1]; ++b)
+            for (int c = 0; c < k[2]; ++c)
+                for (int z = 0; z < o[0]; ++z)
+                    for (int y = 0; y < o[1]; ++y)
+                        for (int x = 0; x < o[2]; ++x)
+                            t[(size_t)((a * k[1] + b) * k[2] + c) * po + (z * o[1] + y) * o[2] + x] =
+                                ((z + a) * d[1] + (y + b)) * d[2] + (x + c);
+    return t;
+}
+
+template <typename T>
+int upload(T** dst, const T* src, size_t n)
+{
+    BX_HIP(hipMalloc(reinterpret_cast<void**>(dst), n * sizeof(T)));
+    BX_HIP(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return BX_OK;
+}
+
+__global__ void subsample_kernel(const float* __restrict__ pts, int n, unsigned long long seed, int cnt, float* __restrict__ out)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= cnt) return;
+    uint64_t k = bx_mix64(seed, (0x200ULL << 32) + (uint64_t)j) % (uint64_t)n;
+    out[(size_t)j * 3] = pts[k * 3]; out[(size_t)j * 3 + 1] = pts[k * 3 + 1]; out[(size_t)j * 3 + 2] = pts[k * 3 + 2];
+}
+
+__global__ void state_reset_kernel(PairState* st, int32_t* err)
+{
+    if (threadIdx.x == 0) {
+        st->m_scale = 0; st->M = 0; st->C = 0; st->best = -1; st->done = 0; st->scales_used = 0; st->num_inliers = 0;
+        st->ransac_iters = 0; st->refine_iters = 0; st->status = 0;
+        for (int i = 0; i < BX_MAX_SCALES; ++i) st->des_r[i] = 0.0;
+        for (int i = 0; i < 16; ++i) { st->T[i] = (i % 5 == 0) ? 1.0 : 0.0; st->Tf[i] = (i % 5 == 0) ? 1.0f : 0.0f; }
+        err[0] = 0;
+    }
+}
+
+__global__ void accumulate_kernel(PairState* st, int scale, const int32_t* skip)
+{
+    if (threadIdx.x == 0 && !(skip && *skip)) { st->M += st->m_scale; st->scales_used = scale + 1; }
+}
+
+__global__ void early_exit_kernel(PairState* st, int min_inliers)
+{
+    if (threadIdx.x == 0) st->done = st->num_inliers >= min_inliers ? 1 : 0;
+}
+
+__global__ void pose_to_float_kernel(PairState* st)
+{
+    if (threadIdx.x < 16) st->Tf[threadIdx.x] = (float)st->T[threadIdx.x];
+}
+
+__global__ void finalize_kernel(const PairState* st, const int32_t* err, int refine, int nscales, bx_result* out)
+{
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 16; ++i) out->pose[i] = refine ? (double)st->Tf[i] : st->T[i];
+        out->num_inliers = st->num_inliers;
+        out->num_mutual = st->M;
+        out->num_inlier_ind = st->C;
+        out->scales_used = st->scales_used;
+        out->ransac_iters = st->ransac_iters;
+        out->refine_iters = st->refine_iters;
+        out->status = err[0];
+        out->reserved = 0;
+        for (int i = 0; i < BX_MAX_SCALES; ++i) out->des_r[i] = i < nscales ? (float)st->des_r[i] : 0.0f;
+    }
+}
+
+int check_ctx(bx_ctx* c, bool need_weights)
+{
+    if (!c) { bx_set_error("null context"); return BX_ERR_ARG; }
+    if (need_weights && !c->weights_loaded) { bx_set_error("weights not loaded (bx_load_weights)"); return BX_ERR_STATE; }
+    return BX_OK;
+}
+
+int desc_stack(bx_ctx* c, hipStream_t s, const float* feat, int K, float* desc, float* equi, float* x_out)
+{
+    const float* in = feat;
+    float* bufs[2] = {c->act0, c->act1};
+    int rc;
+    for (int l = 0; l < BX_NDESC; ++l) {
+        float* out = bufs[l & 1];
+        if ((rc = bxk_conv(c, s, 0, l, in, nullptr, K, out)) != BX_OK) return rc;
+        in = out;
+    }
+    if (x_out) BX_HIP(hipMemcpyAsync(x_out, in, sizeof(float) * (size_t)K * 2 * BX_EA * 16, hipMemcpyDeviceToDevice, s));
+    return bxk_desc_head(c, s, in, K, desc, equi);
+}
+
+int pose_stack(bx_ctx* c, hipStream_t s, const float* s_equi, const float* t_equi, const int32_t* s_mids, const int32_t* t_mids,
+               const int32_t* m_dev, int max_m, float* ind, float* logits_out)
+{
+    int rc;
+    if ((rc = bxk_cost_l1(c, s, s_equi, t_equi, s_mids, t_mids, m_dev, max_m, c->act0)) != BX_OK) return rc;
+    float* bufs[2] = {c->act0, c->act1};
+    const float* in = c->act0;
+    for (int l = 1; l < BX_NPOSE; ++l) {
+        float* out = bufs[l & 1];
+        if ((rc = bxk_conv(c, s, 1, l, in, m_dev, max_m, out)) != BX_OK) return rc;
+        in = out;
+    }
+    if (logits_out) BX_HIP(hipMemcpyAsync(logits_out, in, sizeof(float) * (size_t)max_m * 2 * 16, hipMemcpyDeviceToDevice, s));
+    return bxk_soft_argmax(s, in, m_dev, max_m, ind, c->skip);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* bx_last_error(void) { return g_err; }
+
+int bx_create(int device_id, const bx_params* params, bx_ctx** out)
+{
+    if (!params || !out) { bx_set_error("bx_create: null argument"); return BX_ERR_ARG; }
+    const bx_params& p = *params;
+    if (p.rad_n != BX_RAD || p.ele_n != BX_ELE || p.azi_n != BX_AZI) {
+        bx_set_error("bx_create: only rad_n=3, ele_n=7, azi_n=20 are supported (got %d %d %d)", p.rad_n, p.ele_n, p.azi_n);
+        return BX_ERR_ARG;
+    }
+    if (p.num_fps < 1 || p.num_points_per_patch < 2 || p.num_scales < 1 || p.num_scales > BX_MAX_SCALES || p.max_points < 1 ||
+        p.num_points_radius_estimate < 1 || p.voxel_sample < 1 || p.voxel_sample > 16) {
+        bx_set_error("bx_create: invalid parameters");
+        return BX_ERR_ARG;
+    }
+    BX_HIP(hipSetDevice(device_id));
+    bx_ctx* c = new bx_ctx();
+    memset(c, 0, sizeof(*c));
+    c->device = device_id;
+    c->p = p;
+    size_t total = 0;
+    carve(c, nullptr, &total);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->arena), total);
+    if (e != hipSuccess) {
+        bx_set_error("bx_create: workspace hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
+        delete c;
+        return BX_ERR_HIP;
+    }
+    c->arena_bytes = (int64_t)total;
+    carve(c, c->arena, &total);
+    BX_HIP(hipMemset(c->state, 0, sizeof(PairState)));
+    BX_HIP(hipMemset(c->err_flag, 0, 4 * sizeof(int32_t)));
+    std::vector<float> cen, rot;
+    voxel_tables(cen, rot);
+    int rc;
+    if ((rc = upload(&c->d_centres, cen.data(), cen.size())) != BX_OK) return rc;
+    if ((rc = upload(&c->d_rot, rot.data(), rot.size())) != BX_OK) return rc;
+    std::vector<float> thr(8193);
+    for (int m = 0; m <= 8192; ++m) {
+        // the bisection of models/BUFFERX.py:675-692 only visits des_r = 5 m / 8192; compare value = fp32(des_r*des_r)
+        double r = 5.0 * (double)m / 8192.0;
+        thr[m] = (float)(r * r);
+    }
+    if ((rc = upload(&c->d_rad_thr, thr.data(), thr.size())) != BX_OK) return rc;
+    *out = c;
+    return BX_OK;
+}
+
+int bx_destroy(bx_ctx* c)
+{
+    if (!c) return BX_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(c->arena);
+    (void)hipFree(c->d_centres); (void)hipFree(c->d_rot); (void)hipFree(c->d_rad_thr);
+    (void)hipFree(c->d_pnt_w); (void)hipFree(c->d_pnt_b); (void)hipFree(c->d_pool_w1); (void)hipFree(c->d_pool_b1); (void)hipFree(c->d_pool_w2); (void)hipFree(c->d_pool_b2);
+    for (int i = 0; i < BX_NDESC; ++i) { (void)hipFree(c->desc[i].W); (void)hipFree(c->desc[i].b); (void)hipFree(c->desc[i].tap); }
+    for (int i = 0; i < BX_NPOSE; ++i) { (void)hipFree(c->pose[i].W); (void)hipFree(c->pose[i].b); (void)hipFree(c->pose[i].tap); }
+    delete c;
+    return BX_OK;
+}
+
+int64_t bx_workspace_bytes(const bx_ctx* c) { return c ? c->arena_bytes : 0; }
+
+int bx_load_weights(bx_ctx* c, const bx_weights* w)
+{
+    int rc;
+    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    if (!w) { bx_set_error("bx_load_weights: null"); return BX_ERR_ARG; }
+    BX_HIP(hipSetDevice(c->device));
+    if (c->weights_loaded) { bx_set_error("bx_load_weights: already loaded"); return BX_ERR_STATE; }
+    if ((rc = upload(&c->d_pnt_w, w->pnt_w, 48)) != BX_OK) return rc;
+    if ((rc = upload(&c->d_pnt_b, w->pnt_b, 16)) != BX_OK) return rc;
+    if ((rc = upload(&c->d_pool_w1, w->pool_w1, 512)) != BX_OK) return rc;
+    if ((rc = upload(&c->d_pool_b1, w->pool_b1, 16)) != BX_OK) return rc;
+    if ((rc = upload(&c->d_pool_w2, w->pool_w2, 16)) != BX_OK) return rc;
+    if ((rc = upload(&c->d_pool_b2, w->pool_b2, 1)) != BX_OK) return rc;
+    // Desc: Cylindrical_Net (models/patchnet.py:72-84)
+    static const int dc[BX_NDESC][2] = {{3, 64}, {4, 64}, {4, 128}, {8, 128}, {8, 64}, {4, 64}, {4, 32}, {2, 32}};
+    std::vector<int32_t> ct = cyl_taps();
+    for (int l = 0; l < BX_NDESC; ++l) {
+        ConvLayerDev& L = c->desc[l];
+        L.nchunk = dc[l][0]; L.ntaps = 9; L.p_in = BX_EA; L.p_out = BX_EA; L.cout = dc[l][1]; L.relu = l < BX_NDESC - 1;
+        if ((rc = upload(&L.W, w->desc_w[l], (size_t)L.nchunk * 9 * 16 * L.cout)) != BX_OK) return rc;
+        if ((rc = upload(&L.b, w->desc_b[l], (size_t)L.cout)) != BX_OK) return rc;
+        if ((rc = upload(&L.tap, ct.data(), ct.size())) != BX_OK) return rc;
+    }
+    // Pose: CostNet (models/patchnet.py:196-210) on the [azi, ele-2, azi] cost volume
+    static const int pc[BX_NPOSE][2] = {{2, 32}, {2, 64}, {4, 64}, {4, 128}, {8, 128}, {8, 64}, {4, 64}, {4, 32}, {2, 32}, {2, 20}};
+    int dims[3] = {BX_AZI, BX_ELE - 2, BX_AZI};
+    for (int l = 0; l < BX_NPOSE; ++l) {
+        int k[3] = {3, l < 2 ? 3 : 1, 3};
+        if (l == BX_NPOSE - 1) { k[0] = 2; k[1] = 1; k[2] = 2; }
+        int o[3];
+        std::vector<int32_t> vt = valid_taps(dims, k, o);
+        ConvLayerDev& L = c->pose[l];
+        L.nchunk = pc[l][0]; L.ntaps = k[0] * k[1] * k[2]; L.p_in = dims[0] * dims[1] * dims[2]; L.p_out = o[0] * o[1] * o[2];
+        L.cout = pc[l][1]; L.relu = l < BX_NPOSE - 1;
+        if ((rc = upload(&L.W, w->pose_w[l], (size_t)L.nchunk * L.ntaps * 16 * L.cout)) != BX_OK) return rc;
+        if ((rc = upload(&L.b, w->pose_b[l], (size_t)L.cout)) != BX_OK) return rc;
+        if ((rc = upload(&L.tap, vt.data(), vt.size())) != BX_OK) return rc;
+        for (int i = 0; i < 3; ++i) dims[i] = o[i];
+    }
+    c->weights_loaded = true;
+    return BX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ stages
+int bx_fps(bx_ctx* c, void* stream, const float* xyz, int32_t n, int32_t m, int32_t* idx_out, float* kpts_out)
+{
+    int rc;
+    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    if (!xyz || !idx_out || n < 1 || m < 1) { bx_set_error("bx_fps: bad argument"); return BX_ERR_ARG; }
+    const float* xs[1] = {xyz};
+    int ns[1] = {n};
+    int32_t* is[1] = {idx_out};
+    float* ks[1] = {kpts_out};
+    return bxk_fps(c, (hipStream_t)stream, xs, ns, 1, m, is, ks);
+}
+
+int bx_radius(bx_ctx* c, void* stream, const float* pts, int32_t n_pts, int64_t n_orig, const float* kpts, int32_t nk,
+              const double* thresholds_host, int32_t nthr, double* des_r_out)
+{
+    int rc;
+    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    if (!pts || !kpts || !thresholds_host || !des_r_out || n_pts < 1 || nk < 1) { bx_set_error("bx_radius: bad argument"); return BX_ERR_ARG; }
+    if ((rc = bxk_radius_hist(c, (hipStream_t)stream, pts, n_pts, kpts, nk)) != BX_OK) return rc;
+    for (int i = 0; i < nthr; ++i)
+        if ((rc = bxk_radius_bisect(c, (hipStream_t)stream, n_orig, nk, thresholds_host[i], des_r_out + i)) != BX_OK) return rc;
+    return BX_OK;
+}
+
+int bx_permute(bx_ctx* c, void* stream, const float* pts, const int32_t* perm, int32_t n, float* out)
+{
+    int rc;
+    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    return bx_permute_launch((hipStream_t)stream, pts, perm, n, out, nullptr);
+}
+
+int bx_ball_group(bx_ctx* c, void* stream, const float* pts_perm, int32_t n, const float* kpts, int32_t K, const double* radius,
+                  int32_t P, int32_t* idx_out, float* patches_out)
+{
+    int rc;
+    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    if (!pts_perm || !kpts || !radius || !patches_out) { bx_set_error("bx_ball_group: null argument"); return BX_ERR_ARG; }
+    c->skip = nullptr;
+    return bxk_ball_group(c, (hipStream_t)stream, pts_perm, n, kpts, K, radius, P, idx_out, patches_out);
+}
+
+int bx_patch_features(bx_ctx* c, void* stream, const float* patches, int32_t K, int32_t P, const double* radius, int32_t aligned_z,
+                      float* R_out, float* feat_out)
+{
+    int rc;
+    if ((rc = check_ctx(c, true)) != BX_OK) return rc;
+    if (!patches || !radius || !R_out || !feat_out) { bx_set_error("bx_patch_features: null argument"); return BX_ERR_ARG; }
+    c->skip = nullptr;
+    return bxk_patch_features(c, (hipStream_t)stream, patches, K, P, radius, aligned_z, R_out, feat_out);
+}
+
+int bx_desc_net(bx_ctx* c, void* stream, const float* feat, int32_t K, float* desc_out, float* equi_out, float* x_out)
+{
+    int rc;
+    if ((rc = check_ctx(c, true)) != BX_OK) return rc;
+    if (K > c->p.num_fps) { bx_set_error("bx_desc_net: K=%d exceeds context num_fps=%d", K, c->p.num_fps); return BX_ERR_ARG; }
+    c->skip = nullptr;
+    return desc_stack(c, (hipStream_t)stream, feat, K, desc_out, equi_out, x_out);
+}
+
+int bx_conv_layer(bx_ctx* c, void* stream, int32_t net, int32_t layer, const float* in, int32_t units, float* out)
+{
+    int rc;
+    if ((rc = check_ctx(c, true)) != BX_OK) return rc;
+    if (net == 1 && layer == 0) { bx_set_error("bx_conv_layer: Pose layer 0 consumes the implicit cost volume; use bx_pose_net"); return BX_ERR_ARG; }
+    c->skip = nullptr;
+    return bxk_conv(c, (hipStream_t)stream, net, layer, in, nullptr, units, out);
+}
+
+int bx_mutual(bx_ctx* c, void* stream, const float* src_des, int32_t ns, const float* tgt_des, int32_t nt, int32_t* s_mids,
+              int32_t* t_mids, int32_t* count_out)
+{
+    int rc;
+    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    if (ns > c->p.num_fps || nt > c->p.num_fps) { bx_set_error("bx_mutual: more descriptors than num_fps"); return BX_ERR_ARG; }
+    c->skip = nullptr;
+    return bxk_mutual(c, (hipStream_t)stream, src_des, ns, tgt_des, nt, s_mids, t_mids, count_out);
+}
+
+int bx_pose_net(bx_ctx* c, void* stream, const float* s_equi, const float* t_equi, const int32_t* s_mids, const int32_t* t_mids,
+                const int32_t* m_dev, int32_t max_m, float* ind_out, float* logits_out)
+{
+    int rc;
+    if ((rc = check_ctx(c, true)) != BX_OK) return rc;
+    if (max_m > c->p.num_fps) { bx_set_error("bx_pose_net: max_m exceeds num_fps"); return BX_ERR_ARG; }
+    c->skip = nullptr;
+    return pose_stack(c, (hipStream_t)stream, s_equi, t_equi, s_mids, t_mids, m_dev, max_m, ind_out, logits_out);
+}
+
+int bx_hypotheses(bx_ctx* c, void* stream, const float* ind, const int32_t* s_mids, const int32_t* t_mids, const int32_t* m_dev,
+                  int32_t max_m, const float* s_R, const float* t_R, const float* s_kpts, const float* t_kpts, float* R_out,
+                  float* t_out, float* ss_out, float* tt_out)
+{
+    int rc;
+    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    return bxk_hypotheses((hipStream_t)stream, ind, s_mids, t_mids, m_dev, max_m, s_R, t_R, s_kpts, t_kpts, R_out, t_out, ss_out,
+                          tt_out, nullptr, nullptr);
+}
+
+int bx_consensus(bx_ctx* c, void* stream, const float* R, const float* t, const float* ss, const float* tt, const int32_t* M_dev,
+                 int32_t max_M, int32_t* inlier_out, int32_t* count_out, int32_t* best_out)
+{
+    int rc;
+    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    if (max_M > c->p.num_fps * c->p.num_scales) { bx_set_error("bx_consensus: max_M exceeds num_fps*num_scales"); return BX_ERR_ARG; }
+    c->skip = nullptr;
+    return bxk_consensus(c, (hipStream_t)stream, R, t, ss, tt, M_dev, max_M, inlier_out, count_out, best_out);
+}
+
+int bx_ransac(bx_ctx* c, void* stream, const float* ss, const float* tt, const int32_t* corr, const int32_t* C_dev, int32_t max_C,
+              uint64_t seed, double* T_out, int32_t* info_out)
+{
+    int rc;
+    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    return bxk_ransac(c, (hipStream_t)stream, ss, tt, corr, C_dev, max_C, seed, T_out, info_out, nullptr);
+}
+
+int bx_refine(bx_ctx* c, void* stream, const float* ss, const float* tt, const int32_t* M_dev, int32_t max_M, float* T_io,
+              int32_t* iters_out)
+{
+    int rc;
+    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    if (max_M > c->p.num_fps * c->p.num_scales) { bx_set_error("bx_refine: max_M exceeds num_fps*num_scales"); return BX_ERR_ARG; }
+    return bxk_refine(c, (hipStream_t)stream, ss, tt, M_dev, max_M, T_io, iters_out);
+}
+
+// ------------------------------------------------------------------------------------------------ whole pair
+int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, const float* tgt, int32_t n_tgt, int32_t aligned_z,
+                     const int32_t* perm_src, const int32_t* perm_tgt, uint64_t seed, bx_result* result)
+{
+    int rc;
+    if ((rc = check_ctx(c, true)) != BX_OK) return rc;
+    if (!src || !tgt || !perm_src || !perm_tgt || !result) { bx_set_error("bx_register_pair: null argument"); return BX_ERR_ARG; }
+    const bx_params& p = c->p;
+    if (n_src < 1 || n_tgt < 1 || n_src > p.max_points || n_tgt > p.max_points) {
+        bx_set_error("bx_register_pair: cloud sizes %d/%d outside [1, max_points=%d]", n_src, n_tgt, p.max_points);
+        return BX_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int K = p.num_fps, P = p.num_points_per_patch, S = p.num_scales, NK = p.num_points_radius_estimate;
+    const int KM = K > NK ? K : NK;
+    PairState* st = c->state;
+    c->skip = nullptr;
+    hipLaunchKernelGGL(state_reset_kernel, dim3(1), dim3(64), 0, s, st, c->err_flag);
+
+    // (1) keypoints: ONE furthest-point sampling per cloud; FPS(nk) is a prefix of FPS(K)
+    const float* clouds[2] = {src, tgt};
+    const int ns[2] = {n_src, n_tgt};
+    const int32_t* perms[2] = {perm_src, perm_tgt};
+    if ((rc = bxk_fps(c, s, clouds, ns, 2, KM, c->fps_idx, c->kpts)) != BX_OK) return rc;
+
+    // (2) radius estimation histogram: the LARGER cloud and its keypoints (models/BUFFERX.py:654-665), once per pair
+    const int big = n_src > n_tgt ? 0 : 1;
+    const float* rpts = clouds[big];
+    int rn = ns[big];
+    if (rn > 200000) {
+        hipLaunchKernelGGL(subsample_kernel, dim3((200000 + 255) / 256), dim3(256), 0, s, clouds[big], rn, (unsigned long long)seed, 200000, c->sub_pts);
+        rpts = c->sub_pts;
+        rn = 200000;
+    }
+    if ((rc = bxk_radius_hist(c, s, rpts, rn, c->kpts[big], NK)) != BX_OK) return rc;
+
+    const bool early = p.enable_early_exit != 0;
+    int ransac_calls = 0;
+    for (int i = 0; i < S; ++i) {
+        c->skip = (early && i > 0) ? &st->done : nullptr;
+        if ((rc = bxk_radius_bisect(c, s, (int64_t)ns[big], NK, p.search_radius_thresholds[i], &st->des_r[i])) != BX_OK) return rc;
+        for (int cl = 0; cl < 2; ++cl) {
+            if ((rc = bx_permute_launch(s, clouds[cl], perms[cl] + (size_t)i * ns[cl], ns[cl], c->pts_perm, c->skip)) != BX_OK) return rc;
+            if ((rc = bxk_ball_group(c, s, c->pts_perm, ns[cl], c->kpts[cl], K, &st->des_r[i], P, nullptr, c->patches)) != BX_OK) return rc;
+            if ((rc = bxk_patch_features(c, s, c->patches, K, P, &st->des_r[i], aligned_z, c->Rpatch[cl], c->feat)) != BX_OK) return rc;
+            if ((rc = desc_stack(c, s, c->feat, K, c->desc_out[cl], c->equi[cl], nullptr)) != BX_OK) return rc;
+        }
+        if ((rc = bxk_mutual(c, s, c->desc_out[0], K, c->desc_out[1], K, c->s_mids, c->t_mids, &st->m_scale)) != BX_OK) return rc;
+        if ((rc = pose_stack(c, s, c->equi[0], c->equi[1], c->s_mids, c->t_mids, &st->m_scale, K, c->ind, nullptr)) != BX_OK) return rc;
+        if ((rc = bxk_hypotheses(s, c->ind, c->s_mids, c->t_mids, &st->m_scale, K, c->Rpatch[0], c->Rpatch[1], c->kpts[0], c->kpts[1],
+                                 c->R_cat, c->t_cat, c->ss_cat, c->tt_cat, &st->M, c->skip)) != BX_OK) return rc;
+        hipLaunchKernelGGL(accumulate_kernel, dim3(1), dim3(64), 0, s, st, i, c->skip);
+        if ((rc = bxk_consensus(c, s, c->R_cat, c->t_cat, c->ss_cat, c->tt_cat, &st->M, (i + 1) * K, c->inlier_ind, &st->C, &st->best)) != BX_OK) return rc;
+        if (early && i == 0) {
+            if ((rc = bxk_ransac(c, s, c->ss_cat, c->tt_cat, c->inlier_ind, &st->C, K, bx_mix64(seed, 0x5AC0000ULL + ransac_calls), nullptr, nullptr, nullptr)) != BX_OK) return rc;
+            ++ransac_calls;
+            hipLaunchKernelGGL(early_exit_kernel, dim3(1), dim3(64), 0, s, st, p.early_exit_min_inliers);
+        }
+    }
+    // final pose estimation unless the early exit was taken (models/BUFFERX.py:449-457)
+    if ((rc = bxk_ransac(c, s, c->ss_cat, c->tt_cat, c->inlier_ind, &st->C, S * K, bx_mix64(seed, 0x5AC0000ULL + ransac_calls), nullptr, nullptr,
+                         early ? &st->done : nullptr)) != BX_OK) return rc;
+    c->skip = nullptr;
+    if (p.pose_refine) {
+        hipLaunchKernelGGL(pose_to_float_kernel, dim3(1), dim3(64), 0, s, st);
+        if ((rc = bxk_refine(c, s, c->ss_cat, c->tt_cat, &st->M, S * K, st->Tf, &st->refine_iters)) != BX_OK) return rc;
+    }
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, s, st, c->err_flag, p.pose_refine, S, c->result_dev);
+    BX_LAUNCH_CHECK();
+    BX_HIP(hipMemcpyAsync(result, c->result_dev, sizeof(bx_result), hipMemcpyDeviceToHost, s));
+    return BX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,368 @@
+// bx_common.h -- internal declarations shared by the HIP translation units of libbufferx_hip.so.
+// gfx950 (MI355X / CDNA4) only: 64-lane wavefronts, f32 MFMA, 160 KiB LDS.  Build with -ffp-contract=off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/bufferx.h"
+
+#define BX_PI_F 3.14159274101257324219f
+#define BX_WAVE 64
+
+void bx_set_error(const char* fmt, ...);
+#define BX_HIP(call)                                                                      \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess) {                                                          \
+            bx_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+            return BX_ERR_HIP;                                                            \
+        }                                                                                 \
+    } while (0)
+#define BX_LAUNCH_CHECK() BX_HIP(hipGetLastError())
+
+// ------------------------------------------------------------------ geometry constants
+constexpr int BX_RAD = 3, BX_ELE = 7, BX_AZI = 20;
+constexpr int BX_EA = BX_ELE * BX_AZI;          // 140 positions of the cylindrical map
+constexpr int BX_VOX = BX_RAD * BX_EA;          // 420 voxels
+constexpr int BX_NDESC = 8, BX_NPOSE = 10;
+
+struct ConvLayerDev {
+    float* W;        // [nchunk][ntaps][16][cout]
+    float* b;        // [cout]
+    int32_t* tap;    // [ntaps][p_out]
+    int nchunk, ntaps, p_in, p_out, cout, relu;
+};
+
+// device-side per-pair state written/read by the pipeline kernels (no host round trips)
+struct PairState {
+    int32_t m_scale;        // mutual matches of the current scale
+    int32_t M;              // accumulated matches
+    int32_t C;              // |inlier_ind|
+    int32_t best;           // best hypothesis
+    int32_t done;           // early exit taken
+    int32_t scales_used;
+    int32_t num_inliers;
+    int32_t ransac_iters;
+    int32_t refine_iters;
+    int32_t status;
+    int32_t pad[2];
+    double des_r[BX_MAX_SCALES];
+    double T[16];           // RANSAC pose
+    float Tf[16];           // refined pose
+    // ransac scan state
+    int32_t r_best_inl;
+    int32_t r_est_k;
+    double r_best_rmse;
+    int32_t r_itr;
+    int32_t r_pad;
+};
+
+struct bx_ctx {
+    int device;
+    bx_params p;
+    bool weights_loaded;
+    // constants
+    float* d_centres;   // [420][3]
+    float* d_rot;       // [20][4]
+    float* d_rad_thr;   // [8193] radius-estimation thresholds (float)(r_m^2)
+    float *d_pnt_w, *d_pnt_b, *d_pool_w1, *d_pool_b1, *d_pool_w2, *d_pool_b2;
+    ConvLayerDev desc[BX_NDESC];
+    ConvLayerDev pose[BX_NPOSE];
+    // workspace arena
+    char* arena;
+    int64_t arena_bytes;
+    // carved buffers (see bx_api.hip)
+    float *act0, *act1;                 // conv ping-pong
+    float* patches;                     // [K][P][3]
+    float* feat;                        // [K][3][140][16]
+    float* pts_perm;                    // [max_points][3]
+    int32_t* fps_idx[2];                // per cloud [max(K,nk)]
+    float* kpts[2];                     // [K][3]
+    float* kpts_r[2];                   // radius-estimation keypoints [nk][3]
+    float* desc_out[2];                 // [K][32]
+    float* equi[2];                     // [K][140][32]
+    float* Rpatch[2];                   // [K][9]
+    unsigned long long* nn_key[2];      // [K]
+    int32_t *s_mids, *t_mids;           // [K]
+    float* ind;                         // [K]
+    float *R_cat, *t_cat, *ss_cat, *tt_cat;  // [S*K][..]
+    int32_t* cons_cnt;                  // [S*K]
+    float* cons_thr;                    // [S*K]
+    int32_t* inlier_ind;                // [S*K]
+    unsigned long long* rad_hist;       // [8200]
+    float* fps_dist;                    // [2][max_points]  (unused by register path; kept for generic path)
+    unsigned long long* fps_slots;      // cross-workgroup exchange granules
+    int32_t* ransac_inl;                // [RANSAC_BATCH]
+    double* ransac_err;                 // [RANSAC_BATCH]
+    double* ransac_T;                   // [RANSAC_BATCH][12]
+    float* refine_ws;                   // [8][S*K]
+    int32_t* refine_sel;                // [S*K]
+    float* sub_pts;                     // [200000][3] subsample buffer for radius estimation
+    PairState* state;                   // device
+    bx_result* result_dev;              // device staging of the result
+    int32_t* err_flag;                  // device error flag
+    const int32_t* skip;                // device flag: non-zero => pipeline kernels return immediately (early exit)
+};
+
+constexpr int BX_RANSAC_BATCH = 4096;
+
+// ------------------------------------------------------------------ kernel launchers (one per .hip file)
+int bxk_fps(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* n, int nclouds, int m, int32_t* const* idx_out,
+            float* const* kpts_out);
+int bxk_gather_rows(hipStream_t s, const float* pts, const int32_t* idx, int n, float* out);
+int bxk_radius_hist(bx_ctx* c, hipStream_t s, const float* pts, int n_pts, const float* kpts, int nk);
+int bxk_radius_bisect(bx_ctx* c, hipStream_t s, int64_t n_orig, int nk, double threshold, double* des_r_out);
+int bxk_ball_group(bx_ctx* c, hipStream_t s, const float* pts_perm, int n, const float* kpts, int K, const double* radius,
+                   int P, int32_t* idx_out, float* patches_out);
+int bxk_patch_features(bx_ctx* c, hipStream_t s, const float* patches, int K, int P, const double* radius, int aligned,
+                       float* R_out, float* feat_out);
+int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, const int32_t* units_dev, int max_units,
+             float* out);
+int bxk_cost_l1(bx_ctx* c, hipStream_t s, const float* s_equi, const float* t_equi, const int32_t* s_mids,
+                const int32_t* t_mids, const int32_t* m_dev, int max_m, float* out);
+int bxk_desc_head(bx_ctx* c, hipStream_t s, const float* x, int K, float* desc, float* equi);
+int bxk_mutual(bx_ctx* c, hipStream_t s, const float* sd, int ns, const float* td, int nt, int32_t* s_mids, int32_t* t_mids,
+               int32_t* count_out);
+int bxk_soft_argmax(hipStream_t s, const float* logits, const int32_t* m_dev, int max_m, float* ind, const int32_t* skip);
+int bxk_hypotheses(hipStream_t s, const float* ind, const int32_t* s_mids, const int32_t* t_mids, const int32_t* m_dev,
+                   int max_m, const float* s_R, const float* t_R, const float* s_k, const float* t_k, float* R_out,
+                   float* t_out, float* ss_out, float* tt_out, const int32_t* base_dev, const int32_t* skip);
+int bx_permute_launch(hipStream_t s, const float* pts, const int32_t* perm, int n, float* out, const int32_t* skip);
+int bxk_consensus(bx_ctx* c, hipStream_t s, const float* R, const float* t, const float* ss, const float* tt,
+                  const int32_t* M_dev, int max_M, int32_t* inlier_out, int32_t* count_out, int32_t* best_out);
+int bxk_ransac(bx_ctx* c, hipStream_t s, const float* ss, const float* tt, const int32_t* corr, const int32_t* C_dev,
+               int max_C, uint64_t seed, double* T_out, int32_t* info_out, const int32_t* skip_flag);
+int bxk_refine(bx_ctx* c, hipStream_t s, const float* ss, const float* tt, const int32_t* M_dev, int max_M, float* T_io,
+               int32_t* iters_out);
+
+#ifdef __HIPCC__
+// ------------------------------------------------------------------ device helpers
+__host__ __device__ __forceinline__ uint64_t bx_mix64(uint64_t seed, uint64_t ctr)
+{
+    uint64_t z = seed + 0x9E3779B97F4A7C15ULL * (ctr + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// xor-butterfly all-reduce sums over the 64 lanes ("wave order" of the arithmetic contract)
+__device__ __forceinline__ float bx_wave_sum(float v)
+{
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = v + __shfl_xor(v, s, 64);
+    return v;
+}
+__device__ __forceinline__ double bx_wave_sum(double v)
+{
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = v + __shfl_xor(v, s, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned long long bx_wave_max(unsigned long long v)
+{
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        unsigned long long o = __shfl_xor(v, s, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int bx_wave_sum_i(int v)
+{
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = v + __shfl_xor(v, s, 64);
+    return v;
+}
+// exclusive prefix sum over the wave
+__device__ __forceinline__ int bx_wave_excl_scan(int v, int lane)
+{
+    int x = v;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        int y = __shfl_up(x, s, 64);
+        if (lane >= s) x += y;
+    }
+    return x - v;
+}
+
+// ---- deterministic binary64 elementary functions (same series as oracle/bxo_detmath.h, written for the device)
+__device__ __forceinline__ double bxd_pow2i(int k) { return __longlong_as_double((long long)(k + 1023) << 52); }
+
+__device__ inline double bxd_exp(double x)
+{
+    if (x < -700.0) return 0.0;
+    if (x > 700.0) x = 700.0;
+    double kf = floor(x * 1.4426950408889634074 + 0.5);
+    double r = (x - kf * 6.93147180369123816490e-01) - kf * 1.90821492927058770002e-10;
+    double p = 1.0 / 87178291200.0;
+    p = p * r + 1.0 / 6227020800.0;
+    p = p * r + 1.0 / 479001600.0;
+    p = p * r + 1.0 / 39916800.0;
+    p = p * r + 1.0 / 3628800.0;
+    p = p * r + 1.0 / 362880.0;
+    p = p * r + 1.0 / 40320.0;
+    p = p * r + 1.0 / 5040.0;
+    p = p * r + 1.0 / 720.0;
+    p = p * r + 1.0 / 120.0;
+    p = p * r + 1.0 / 24.0;
+    p = p * r + 1.0 / 6.0;
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    return p * bxd_pow2i((int)kf);
+}
+
+__device__ inline void bxd_sincos(double x, double* s, double* c)
+{
+    double kf = floor(x * 0.63661977236758134308 + 0.5);
+    double r = (x - kf * 1.57079632673412561417e+00) - kf * 6.07710050650619224932e-11;
+    r = r - kf * 2.02226624879595063154e-21;
+    double r2 = r * r;
+    double ps = -1.0 / 121645100408832000.0;
+    ps = ps * r2 + 1.0 / 355687428096000.0;
+    ps = ps * r2 - 1.0 / 1307674368000.0;
+    ps = ps * r2 + 1.0 / 6227020800.0;
+    ps = ps * r2 - 1.0 / 39916800.0;
+    ps = ps * r2 + 1.0 / 362880.0;
+    ps = ps * r2 - 1.0 / 5040.0;
+    ps = ps * r2 + 1.0 / 120.0;
+    ps = ps * r2 - 1.0 / 6.0;
+    ps = ps * r2 + 1.0;
+    double sn = ps * r;
+    double pc = -1.0 / 6402373705728000.0;
+    pc = pc * r2 + 1.0 / 20922789888000.0;
+    pc = pc * r2 - 1.0 / 87178291200.0;
+    pc = pc * r2 + 1.0 / 479001600.0;
+    pc = pc * r2 - 1.0 / 3628800.0;
+    pc = pc * r2 + 1.0 / 40320.0;
+    pc = pc * r2 - 1.0 / 720.0;
+    pc = pc * r2 + 1.0 / 24.0;
+    pc = pc * r2 - 0.5;
+    pc = pc * r2 + 1.0;
+    double cs = pc;
+    long long k = (long long)kf;
+    int q = (int)(k & 3);
+    if (q == 0) { *s = sn; *c = cs; }
+    else if (q == 1) { *s = cs; *c = -sn; }
+    else if (q == 2) { *s = -sn; *c = -cs; }
+    else { *s = -cs; *c = sn; }
+}
+
+__device__ inline double bxd_asin_small(double t)
+{
+    double t2 = t * t;
+    double term = t;
+    double sum = t;
+    for (int n = 1; n <= 30; ++n) {
+        term = term * t2 * ((double)(2 * n - 1) / (double)(2 * n));
+        sum = sum + term / (double)(2 * n + 1);
+    }
+    return sum;
+}
+
+__device__ inline double bxd_acos(double x)
+{
+    const double PI = 3.14159265358979323846;
+    if (x > 1.0) x = 1.0;
+    if (x < -1.0) x = -1.0;
+    double ax = x < 0 ? -x : x;
+    if (ax <= 0.5) return PI * 0.5 - bxd_asin_small(x);
+    double z = (1.0 - ax) * 0.5;
+    double a = 2.0 * bxd_asin_small(sqrt(z));
+    return x > 0 ? a : PI - a;
+}
+
+__device__ inline double bxd_log(double x)
+{
+    unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    int e = (int)((u >> 52) & 0x7ff) - 1023;
+    double m = __longlong_as_double((long long)((u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL));
+    if (m > 1.41421356237309504880) { m = m * 0.5; e += 1; }
+    double f = (m - 1.0) / (m + 1.0);
+    double f2 = f * f;
+    double sum = 0.0;
+    for (int n = 14; n >= 0; --n) sum = sum * f2 + 1.0 / (double)(2 * n + 1);
+    double lm = 2.0 * f * sum;
+    return ((double)e * 6.93147180369123816490e-01 + lm) + (double)e * 1.90821492927058770002e-10;
+}
+
+// symmetric 3x3 Jacobi (binary64, 10 fixed sweeps); v = eigenvectors as columns
+__device__ inline void bxd_jacobi3(double a[9], double v[9], double w[3])
+{
+    for (int i = 0; i < 9; ++i) v[i] = 0.0;
+    v[0] = v[4] = v[8] = 1.0;
+    for (int sweep = 0; sweep < 10; ++sweep) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int p = (r == 2) ? 1 : 0;
+            const int q = (r == 0) ? 1 : 2;
+            double apq = a[p * 3 + q];
+            if (apq == 0.0) continue;
+            double app = a[p * 3 + p], aqq = a[q * 3 + q];
+            double theta = (aqq - app) / (2.0 * apq);
+            double at = theta < 0 ? -theta : theta;
+            double t = 1.0 / (at + sqrt(theta * theta + 1.0));
+            if (theta < 0) t = -t;
+            double c = 1.0 / sqrt(t * t + 1.0);
+            double s = t * c;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                double akp = a[k * 3 + p], akq = a[k * 3 + q];
+                a[k * 3 + p] = c * akp - s * akq;
+                a[k * 3 + q] = s * akp + c * akq;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                double apk = a[p * 3 + k], aqk = a[q * 3 + k];
+                a[p * 3 + k] = c * apk - s * aqk;
+                a[q * 3 + k] = s * apk + c * aqk;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                double vkp = v[k * 3 + p], vkq = v[k * 3 + q];
+                v[k * 3 + p] = c * vkp - s * vkq;
+                v[k * 3 + q] = s * vkp + c * vkq;
+            }
+        }
+    }
+    w[0] = a[0]; w[1] = a[4]; w[2] = a[8];
+}
+
+// Kabsch rotation from H = sum a b^T (a source, b target); returns 0 on rank < 2.
+__device__ inline int bxd_kabsch_from_H(const double H[9], double R[9])
+{
+    double hth[9], V[9], w[3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            hth[i * 3 + j] = (H[0 * 3 + i] * H[0 * 3 + j] + H[1 * 3 + i] * H[1 * 3 + j]) + H[2 * 3 + i] * H[2 * 3 + j];
+    bxd_jacobi3(hth, V, w);
+    int o0 = 0, o1 = 1, o2 = 2, tmp;
+    if (w[o1] > w[o0]) { tmp = o0; o0 = o1; o1 = tmp; }
+    if (w[o2] > w[o0]) { tmp = o0; o0 = o2; o2 = tmp; }
+    if (w[o2] > w[o1]) { tmp = o1; o1 = o2; o2 = tmp; }
+    (void)o2;
+    double v1[3] = {V[0 * 3 + o0], V[1 * 3 + o0], V[2 * 3 + o0]};
+    double v2[3] = {V[0 * 3 + o1], V[1 * 3 + o1], V[2 * 3 + o1]};
+    double l1 = w[o0], l2 = w[o1];
+    if (!(l1 > 0.0) || !(l2 > l1 * 1e-24)) return 0;
+    double u1[3], u2[3];
+    for (int i = 0; i < 3; ++i) {
+        u1[i] = (H[i * 3 + 0] * v1[0] + H[i * 3 + 1] * v1[1]) + H[i * 3 + 2] * v1[2];
+        u2[i] = (H[i * 3 + 0] * v2[0] + H[i * 3 + 1] * v2[1]) + H[i * 3 + 2] * v2[2];
+    }
+    double n1 = sqrt((u1[0] * u1[0] + u1[1] * u1[1]) + u1[2] * u1[2]);
+    if (!(n1 > 0.0)) return 0;
+    for (int i = 0; i < 3; ++i) u1[i] = u1[i] / n1;
+    double d12 = (u1[0] * u2[0] + u1[1] * u2[1]) + u1[2] * u2[2];
+    for (int i = 0; i < 3; ++i) u2[i] = u2[i] - d12 * u1[i];
+    double n2 = sqrt((u2[0] * u2[0] + u2[1] * u2[1]) + u2[2] * u2[2]);
+    if (!(n2 > 0.0)) return 0;
+    for (int i = 0; i < 3; ++i) u2[i] = u2[i] / n2;
+    double u3[3] = {u1[1] * u2[2] - u1[2] * u2[1], u1[2] * u2[0] - u1[0] * u2[2], u1[0] * u2[1] - u1[1] * u2[0]};
+    double v3[3] = {v1[1] * v2[2] - v1[2] * v2[1], v1[2] * v2[0] - v1[0] * v2[2], v1[0] * v2[1] - v1[1] * v2[0]};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            R[i * 3 + j] = (v1[i] * u1[j] + v2[i] * u2[j]) + v3[i] * u3[j];
+    return 1;
+}
+#endif  // __HIPCC__

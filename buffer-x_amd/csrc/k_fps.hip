@@ -1,0 +1,281 @@
+// k_fps.hip -- furthest point sampling + keypoint gather for gfx950.
+//
+// Replaces pointnet2_ops.furthest_point_sample / gather_operation (reference call sites
+// models/BUFFERX.py:286-290, 338-346; semantics SURVEY.md A.1).  The reference runs ONE thread block per
+// cloud and re-runs FPS (1+S) times per cloud; here FPS runs once per cloud (FPS(2000) is a prefix of
+// FPS(num_fps)) and both clouds of a pair run in one launch.
+//
+// Design (latency-bound: m strictly dependent arg-max steps):
+//   * each workgroup (1024 threads = 16 waves) keeps PPT points per thread -- xyz AND the running
+//     min-distance -- in VGPRs for the whole kernel: no memory traffic inside the iteration loop.
+//     16 K points fill half of a CU's vector register file, so a cloud of N points is split over
+//     G = ceil(N / 16384) workgroups (CUs).
+//   * per iteration: thread-local scan (strict '>' == upstream per-thread rule), 64-bit key
+//     {fp32 bits of d, ~tie-break} max-reduced over the wave with lane shuffles, one LDS record per
+//     wave, one s_barrier.  The tie-break reproduces the upstream block-tree rule for T = 512
+//     (lower k mod T, then lower k) -- see oracle/bx_oracle.c bxo_fps.
+//   * G > 1: workgroups exchange their winner {key, x, y, z} through 8-byte {epoch, value} granules
+//     written with agent-scope relaxed (sc1, write-through) stores and polled with agent-scope relaxed
+//     loads -- the "R2 granule" hand-off of the CDNA4 guide: no fence, placement independent, spins
+//     bounded.  Slots are double-buffered by iteration parity and zeroed by a memset node before launch.
+#include "bx_common.h"
+
+namespace {
+
+constexpr int FPS_THREADS = 1024;
+constexpr int FPS_WAVES = FPS_THREADS / 64;
+constexpr int FPS_MAX_G = 16;
+constexpr int FPS_MAX_CLOUDS = 2;
+constexpr unsigned FPS_SPIN_LIMIT = 1u << 24;
+
+struct FpsArgs {
+    const float* xyz[FPS_MAX_CLOUDS];
+    int32_t* idx_out[FPS_MAX_CLOUDS];
+    float* kpts_out[FPS_MAX_CLOUDS];
+    int n[FPS_MAX_CLOUDS];
+    int G[FPS_MAX_CLOUDS];
+    int wg_start[FPS_MAX_CLOUDS + 1];
+    int nclouds;
+    int m;
+    unsigned long long* slots;  // [cloud][parity 2][FPS_MAX_G][5] granules
+    int32_t* err_flag;
+};
+
+struct Rec {
+    long long key;
+    float x, y, z;
+};
+
+template <int PPT>
+__global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
+{
+    __shared__ long long s_key[2][FPS_WAVES];
+    __shared__ float s_xyz[2][FPS_WAVES][3];
+    __shared__ long long s_fkey[2];
+    __shared__ float s_fxyz[2][3];
+
+    int cloud = 0;
+    if (a.nclouds > 1 && (int)blockIdx.x >= a.wg_start[1]) cloud = 1;
+    const int g = blockIdx.x - a.wg_start[cloud];
+    const int G = a.G[cloud];
+    const int n = a.n[cloud];
+    const float* __restrict__ xyz = a.xyz[cloud];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int base = g * (FPS_THREADS * PPT);
+
+    int T = 1, lt = 0;
+    while (T * 2 <= n && T * 2 <= 512) { T *= 2; ++lt; }
+    const unsigned tmask = (unsigned)(T - 1);
+
+    float px[PPT], py[PPT], pz[PPT], td[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        int k = base + i * FPS_THREADS + t;
+        if (k < n) {
+            px[i] = xyz[(size_t)k * 3 + 0];
+            py[i] = xyz[(size_t)k * 3 + 1];
+            pz[i] = xyz[(size_t)k * 3 + 2];
+            float mag = (px[i] * px[i] + py[i] * py[i]) + pz[i] * pz[i];
+            td[i] = (mag <= 1e-3f) ? -1.0f : 1e10f;  // -1 marks "never a candidate" (upstream `continue`)
+        } else {
+            px[i] = 0.f; py[i] = 0.f; pz[i] = 0.f; td[i] = -1.0f;
+        }
+    }
+    float cx = xyz[0], cy = xyz[1], cz = xyz[2];
+    if (g == 0 && t == 0) {
+        a.idx_out[cloud][0] = 0;
+        if (a.kpts_out[cloud]) { a.kpts_out[cloud][0] = cx; a.kpts_out[cloud][1] = cy; a.kpts_out[cloud][2] = cz; }
+    }
+    unsigned long long* slots = a.slots + (size_t)cloud * 2 * FPS_MAX_G * 5;
+
+    for (int j = 1; j < a.m; ++j) {
+        const int par = j & 1;
+        float bd = -1.0f, bx = 0.f, by = 0.f, bz = 0.f;
+        int bi = 0;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            float dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz;
+            float d = (dx * dx + dy * dy) + dz * dz;
+            float d2 = fminf(d, td[i]);
+            td[i] = d2;
+            bool better = d2 > bd;
+            bd = better ? d2 : bd;
+            bi = better ? i : bi;
+            bx = better ? px[i] : bx;
+            by = better ? py[i] : by;
+            bz = better ? pz[i] : bz;
+        }
+        unsigned k = (unsigned)(base + bi * FPS_THREADS + t);
+        unsigned tb = ((k & tmask) << 23) | (k >> lt);
+        long long key = ((long long)__float_as_int(bd) << 32) | (long long)(unsigned)(~tb);
+        // wave max (signed 64-bit)
+        long long wk = key;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+            long long o = __shfl_xor(wk, s, 64);
+            wk = o > wk ? o : wk;
+        }
+        if (key == wk) {  // keys are unique per thread (they embed the point index)
+            s_key[par][wave] = wk;
+            s_xyz[par][wave][0] = bx; s_xyz[par][wave][1] = by; s_xyz[par][wave][2] = bz;
+        }
+        __syncthreads();
+        long long fk;
+        float fx, fy, fz;
+        if (G == 1) {
+            fk = s_key[par][0]; fx = s_xyz[par][0][0]; fy = s_xyz[par][0][1]; fz = s_xyz[par][0][2];
+#pragma unroll
+            for (int w = 1; w < FPS_WAVES; ++w) {
+                long long kk = s_key[par][w];
+                bool b = kk > fk;
+                fk = b ? kk : fk;
+                fx = b ? s_xyz[par][w][0] : fx;
+                fy = b ? s_xyz[par][w][1] : fy;
+                fz = b ? s_xyz[par][w][2] : fz;
+            }
+        } else {
+            if (wave == 0) {
+                // combine the 16 wave records
+                long long k0 = lane < FPS_WAVES ? s_key[par][lane] : (long long)0x8000000000000000LL;
+                long long mk = k0;
+#pragma unroll
+                for (int s = 8; s >= 1; s >>= 1) {
+                    long long o = __shfl_xor(mk, s, 64);
+                    mk = o > mk ? o : mk;
+                }
+                mk = __shfl(mk, 0, 64);
+                // the (unique, or lowest) lane holding the max publishes this workgroup's record
+                unsigned long long bal = __ballot(lane < FPS_WAVES && k0 == mk);
+                int src = __ffsll((long long)bal) - 1;
+                unsigned long long* my = slots + ((size_t)par * FPS_MAX_G + g) * 5;
+                if (lane == src) {
+                    unsigned ep = (unsigned)j;
+                    unsigned v[5] = {(unsigned)((unsigned long long)mk >> 32), (unsigned)((unsigned long long)mk & 0xffffffffu),
+                                     __float_as_uint(s_xyz[par][lane][0]), __float_as_uint(s_xyz[par][lane][1]),
+                                     __float_as_uint(s_xyz[par][lane][2])};
+#pragma unroll
+                    for (int q = 0; q < 5; ++q)
+                        __hip_atomic_store(my + q, ((unsigned long long)ep << 32) | v[q], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // poll all G records (lanes 0..5G-1, one granule each; 5G <= 80 -> two rounds max)
+                unsigned val[2] = {0, 0};
+                bool fail = false;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    int q = lane + r * 64;
+                    bool act = q < 5 * G;
+                    unsigned long long* gp = slots + (size_t)par * FPS_MAX_G * 5 + q;
+                    unsigned spins = 0;
+                    while (true) {
+                        bool ok = true;
+                        if (act) {
+                            unsigned long long x = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            val[r] = (unsigned)x;
+                            ok = (unsigned)(x >> 32) == (unsigned)j;
+                        }
+                        if (__all(ok)) break;
+                        if (++spins > FPS_SPIN_LIMIT) { fail = true; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                if (fail && lane == 0) atomicOr(a.err_flag, 1);
+                // gather record w: granules 5w..5w+4 -> lanes; reduce
+                long long bestk = (long long)0x8000000000000000LL;
+                float ox = 0.f, oy = 0.f, oz = 0.f;
+                for (int w = 0; w < G; ++w) {
+                    int q0 = 5 * w;
+                    unsigned hi = __shfl(q0 < 64 ? val[0] : val[1], q0 & 63, 64);
+                    unsigned lo = __shfl((q0 + 1) < 64 ? val[0] : val[1], (q0 + 1) & 63, 64);
+                    unsigned ux = __shfl((q0 + 2) < 64 ? val[0] : val[1], (q0 + 2) & 63, 64);
+                    unsigned uy = __shfl((q0 + 3) < 64 ? val[0] : val[1], (q0 + 3) & 63, 64);
+                    unsigned uz = __shfl((q0 + 4) < 64 ? val[0] : val[1], (q0 + 4) & 63, 64);
+                    long long kk = (long long)(((unsigned long long)hi << 32) | lo);
+                    if (kk > bestk) { bestk = kk; ox = __uint_as_float(ux); oy = __uint_as_float(uy); oz = __uint_as_float(uz); }
+                }
+                if (lane == 0) {
+                    s_fkey[par] = bestk;
+                    s_fxyz[par][0] = ox; s_fxyz[par][1] = oy; s_fxyz[par][2] = oz;
+                }
+            }
+            __syncthreads();
+            fk = s_fkey[par]; fx = s_fxyz[par][0]; fy = s_fxyz[par][1]; fz = s_fxyz[par][2];
+        }
+        int old;
+        if (fk < 0) {  // no candidate anywhere (all points within 1e-3 of the origin): upstream yields index 0
+            old = 0; fx = xyz[0]; fy = xyz[1]; fz = xyz[2];
+        } else {
+            unsigned tbw = ~(unsigned)((unsigned long long)fk & 0xffffffffu);
+            old = (int)(((tbw & 0x7fffffu) << lt) | (tbw >> 23));
+        }
+        cx = fx; cy = fy; cz = fz;
+        if (g == 0 && t == 0) {
+            a.idx_out[cloud][j] = old;
+            if (a.kpts_out[cloud]) {
+                a.kpts_out[cloud][(size_t)j * 3 + 0] = cx;
+                a.kpts_out[cloud][(size_t)j * 3 + 1] = cy;
+                a.kpts_out[cloud][(size_t)j * 3 + 2] = cz;
+            }
+        }
+    }
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ pts, const int32_t* __restrict__ idx, int n, float* __restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        size_t s = (size_t)idx[i] * 3;
+        out[(size_t)i * 3 + 0] = pts[s + 0];
+        out[(size_t)i * 3 + 1] = pts[s + 1];
+        out[(size_t)i * 3 + 2] = pts[s + 2];
+    }
+}
+
+}  // namespace
+
+int bxk_fps(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* n, int nclouds, int m, int32_t* const* idx_out,
+            float* const* kpts_out)
+{
+    if (nclouds < 1 || nclouds > FPS_MAX_CLOUDS) { bx_set_error("bxk_fps: nclouds"); return BX_ERR_ARG; }
+    FpsArgs a{};
+    a.nclouds = nclouds;
+    a.m = m;
+    a.slots = c->fps_slots;
+    a.err_flag = c->err_flag;
+    int ppt = 4;
+    int total = 0;
+    int nmax = 0;
+    for (int i = 0; i < nclouds; ++i) nmax = n[i] > nmax ? n[i] : nmax;
+    // fewest workgroups first (cross-CU exchange is the expensive part), then the smallest PPT that fits
+    int Gneed = (nmax + FPS_THREADS * 16 - 1) / (FPS_THREADS * 16);
+    if (Gneed < 1) Gneed = 1;
+    if (Gneed > FPS_MAX_G) { bx_set_error("bxk_fps: cloud of %d points exceeds %d", nmax, FPS_MAX_G * FPS_THREADS * 16); return BX_ERR_ARG; }
+    int per_wg = (nmax + Gneed - 1) / Gneed;
+    ppt = per_wg <= FPS_THREADS * 4 ? 4 : (per_wg <= FPS_THREADS * 8 ? 8 : 16);
+    for (int i = 0; i < nclouds; ++i) {
+        if (n[i] < 1) { bx_set_error("bxk_fps: empty cloud"); return BX_ERR_ARG; }
+        a.xyz[i] = xyz[i];
+        a.n[i] = n[i];
+        a.idx_out[i] = idx_out[i];
+        a.kpts_out[i] = kpts_out ? kpts_out[i] : nullptr;
+        a.G[i] = (n[i] + FPS_THREADS * ppt - 1) / (FPS_THREADS * ppt);
+        a.wg_start[i] = total;
+        total += a.G[i];
+    }
+    a.wg_start[nclouds] = total;
+    BX_HIP(hipMemsetAsync(c->fps_slots, 0, sizeof(unsigned long long) * FPS_MAX_CLOUDS * 2 * FPS_MAX_G * 5, s));
+    if (ppt == 4) hipLaunchKernelGGL(fps_kernel<4>, dim3(total), dim3(FPS_THREADS), 0, s, a);
+    else if (ppt == 8) hipLaunchKernelGGL(fps_kernel<8>, dim3(total), dim3(FPS_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(fps_kernel<16>, dim3(total), dim3(FPS_THREADS), 0, s, a);
+    BX_LAUNCH_CHECK();
+    return BX_OK;
+}
+
+int bxk_gather_rows(hipStream_t s, const float* pts, const int32_t* idx, int n, float* out)
+{
+    if (n <= 0) return BX_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, idx, n, out);
+    BX_LAUNCH_CHECK();
+    return BX_OK;
+}

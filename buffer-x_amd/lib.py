@@ -1,0 +1,343 @@
+"""ctypes binding of libbufferx_hip.so (C-ABI: include/bufferx.h).
+
+PyTorch is used only as plumbing: device allocations (`tensor.data_ptr()`), the current HIP stream and
+weight loading.  There is NO fallback: if the HIP library cannot be loaded every entry point raises.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_SO = os.path.join(_CSRC, "libbufferx_hip.so")
+_LIB = None
+
+BX_MAX_SCALES = 8
+
+
+class BxParams(C.Structure):
+    _fields_ = [("num_fps", C.c_int32), ("num_points_per_patch", C.c_int32), ("num_scales", C.c_int32),
+                ("rad_n", C.c_int32), ("azi_n", C.c_int32), ("ele_n", C.c_int32), ("voxel_sample", C.c_int32),
+                ("num_points_radius_estimate", C.c_int32), ("delta", C.c_double),
+                ("search_radius_thresholds", C.c_double * BX_MAX_SCALES),
+                ("dist_th", C.c_double), ("inlier_th", C.c_double), ("similar_th", C.c_double),
+                ("confidence", C.c_double), ("iter_n", C.c_int32), ("enable_early_exit", C.c_int32),
+                ("early_exit_min_inliers", C.c_int32), ("pose_refine", C.c_int32), ("max_points", C.c_int32)]
+
+
+class BxWeights(C.Structure):
+    _fields_ = [("pnt_w", C.c_void_p), ("pnt_b", C.c_void_p), ("pool_w1", C.c_void_p), ("pool_b1", C.c_void_p),
+                ("pool_w2", C.c_void_p), ("pool_b2", C.c_void_p), ("desc_w", C.c_void_p * 8), ("desc_b", C.c_void_p * 8),
+                ("pose_w", C.c_void_p * 10), ("pose_b", C.c_void_p * 10)]
+
+
+class BxResult(C.Structure):
+    _fields_ = [("pose", C.c_double * 16), ("num_inliers", C.c_int32), ("num_mutual", C.c_int32),
+                ("num_inlier_ind", C.c_int32), ("scales_used", C.c_int32), ("ransac_iters", C.c_int32),
+                ("refine_iters", C.c_int32), ("status", C.c_int32), ("reserved", C.c_int32),
+                ("des_r", C.c_float * BX_MAX_SCALES)]
+
+
+EXPORTS = ["bx_create", "bx_destroy", "bx_last_error", "bx_load_weights", "bx_workspace_bytes", "bx_register_pair",
+           "bx_fps", "bx_radius", "bx_permute", "bx_ball_group", "bx_patch_features", "bx_desc_net", "bx_conv_layer",
+           "bx_mutual", "bx_pose_net", "bx_hypotheses", "bx_consensus", "bx_ransac", "bx_refine"]
+
+
+def build(force=False):
+    """Compile every HIP translation unit for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "bufferx.h"))
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if stale or force:
+        subprocess.check_call(["make", "-C", _CSRC, "-j8"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def load():
+    """Load the HIP library; raises (never falls back) when it is missing."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_SO):
+            raise RuntimeError(f"{_SO} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(the HIP path has no CPU fallback)")
+        lib = C.CDLL(_SO)
+        lib.bx_last_error.restype = C.c_char_p
+        lib.bx_workspace_bytes.restype = C.c_int64
+        _LIB = lib
+    return _LIB
+
+
+class BxError(RuntimeError):
+    pass
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise BxError(f"{what} failed (status {rc}): {load().bx_last_error().decode()}")
+
+
+def params_from_cfg(cfg, max_points):
+    p = BxParams()
+    p.num_fps = int(cfg.patch.num_fps)
+    p.num_points_per_patch = int(cfg.patch.num_points_per_patch)
+    p.num_scales = int(cfg.patch.num_scales)
+    p.rad_n, p.azi_n, p.ele_n = int(cfg.patch.rad_n), int(cfg.patch.azi_n), int(cfg.patch.ele_n)
+    p.voxel_sample = int(cfg.patch.voxel_sample)
+    p.num_points_radius_estimate = int(cfg.patch.num_points_radius_estimate)
+    p.delta = float(cfg.patch.delta)
+    thr = list(cfg.patch.search_radius_thresholds)
+    assert len(thr) == p.num_scales, f"num_scales {p.num_scales} != num_thresholds {len(thr)}"  # models/BUFFERX.py:276
+    for i, t in enumerate(thr):
+        p.search_radius_thresholds[i] = float(t)
+    p.dist_th, p.inlier_th = float(cfg.match.dist_th), float(cfg.match.inlier_th)
+    p.similar_th, p.confidence = float(cfg.match.similar_th), float(cfg.match.confidence)
+    p.iter_n = int(cfg.match.iter_n)
+    p.enable_early_exit = int(bool(cfg.match.get("enable_early_exit", True)))
+    p.early_exit_min_inliers = int(cfg.match.get("early_exit_min_inliers", 15))
+    p.pose_refine = int(cfg.test.pose_refine is True)
+    p.max_points = int(max_points)
+    return p
+
+
+def slot_perm():
+    """slot -> logical channel map of one 16-chunk (include/bufferx.h bx_chunk_slot)."""
+    inv = np.zeros(16, np.int64)
+    for c in range(16):
+        inv[4 * (c % 4) + c // 4] = c
+    return inv
+
+
+def chunked_to_logical(x):
+    """[..., 16 slots] -> [..., 16 logical channels]"""
+    inv = slot_perm()
+    out = np.empty_like(x)
+    out[..., inv] = x
+    return out
+
+
+def logical_to_chunked(x):
+    inv = slot_perm()
+    return np.ascontiguousarray(x[..., inv])
+
+
+class Context:
+    """One per in-flight pair: owns the device workspace arena (include/bufferx.h bx_ctx)."""
+
+    def __init__(self, cfg, max_points, device=0, packed_weights=None):
+        import torch
+        self.torch = torch
+        self.lib = load()
+        self.cfg = cfg
+        self.device = device
+        self.params = params_from_cfg(cfg, max_points)
+        self.handle = C.c_void_p()
+        _chk(self.lib.bx_create(C.c_int(device), C.byref(self.params), C.byref(self.handle)), "bx_create")
+        self._keep = []
+        if packed_weights is not None:
+            self.load_weights(packed_weights)
+
+    def close(self):
+        if self.handle:
+            self.lib.bx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def workspace_bytes(self):
+        return int(self.lib.bx_workspace_bytes(self.handle))
+
+    def load_weights(self, pw):
+        w = BxWeights()
+        keep = []
+
+        def ptr(a):
+            a = np.ascontiguousarray(a, np.float32)
+            keep.append(a)
+            return a.ctypes.data_as(C.c_void_p)
+
+        w.pnt_w, w.pnt_b = ptr(pw["pnt_w"]), ptr(pw["pnt_b"])
+        w.pool_w1, w.pool_b1 = ptr(pw["pool_w1"]), ptr(pw["pool_b1"])
+        w.pool_w2, w.pool_b2 = ptr(pw["pool_w2"]), ptr(pw["pool_b2"])
+        for i, L in enumerate(pw["desc"]):
+            w.desc_w[i], w.desc_b[i] = ptr(L["W"]), ptr(L["b"])
+        for i, L in enumerate(pw["pose"]):
+            w.pose_w[i], w.pose_b[i] = ptr(L["W"]), ptr(L["b"])
+        _chk(self.lib.bx_load_weights(self.handle, C.byref(w)), "bx_load_weights")
+
+    # ---------------------------------------------------------------- helpers
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, a, dtype):
+        t = self.torch
+        if isinstance(a, t.Tensor):
+            return a.to(device=f"cuda:{self.device}", dtype=dtype).contiguous()
+        return t.as_tensor(np.ascontiguousarray(a), dtype=dtype, device=f"cuda:{self.device}")
+
+    def _empty(self, shape, dtype):
+        return self.torch.empty(shape, dtype=dtype, device=f"cuda:{self.device}")
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else None
+
+    # ---------------------------------------------------------------- stages (torch tensors in / out)
+    def fps(self, xyz, m):
+        t = self.torch
+        xyz = self._dev(xyz, t.float32)
+        idx = self._empty((m,), t.int32)
+        kp = self._empty((m, 3), t.float32)
+        _chk(self.lib.bx_fps(self.handle, self._stream(), self._p(xyz), C.c_int32(xyz.shape[0]), C.c_int32(m), self._p(idx),
+                             self._p(kp)), "bx_fps")
+        return idx, kp
+
+    def radius(self, pts, n_orig, kpts, thresholds):
+        t = self.torch
+        pts, kpts = self._dev(pts, t.float32), self._dev(kpts, t.float32)
+        thr = (C.c_double * len(thresholds))(*[float(v) for v in thresholds])
+        out = self._empty((len(thresholds),), t.float64)
+        _chk(self.lib.bx_radius(self.handle, self._stream(), self._p(pts), C.c_int32(pts.shape[0]), C.c_int64(n_orig),
+                                self._p(kpts), C.c_int32(kpts.shape[0]), thr, C.c_int32(len(thresholds)), self._p(out)),
+             "bx_radius")
+        return out
+
+    def permute(self, pts, perm):
+        t = self.torch
+        pts, perm = self._dev(pts, t.float32), self._dev(perm, t.int32)
+        out = self._empty(tuple(pts.shape), t.float32)
+        _chk(self.lib.bx_permute(self.handle, self._stream(), self._p(pts), self._p(perm), C.c_int32(pts.shape[0]),
+                                 self._p(out)), "bx_permute")
+        return out
+
+    def ball_group(self, pts_perm, kpts, radius_dev, P, want_idx=True):
+        t = self.torch
+        pts_perm, kpts = self._dev(pts_perm, t.float32), self._dev(kpts, t.float32)
+        radius_dev = self._dev(radius_dev, t.float64).reshape(-1)
+        K = kpts.shape[0]
+        idx = self._empty((K, P), t.int32) if want_idx else None
+        patches = self._empty((K, P, 3), t.float32)
+        _chk(self.lib.bx_ball_group(self.handle, self._stream(), self._p(pts_perm), C.c_int32(pts_perm.shape[0]), self._p(kpts),
+                                    C.c_int32(K), self._p(radius_dev), C.c_int32(P), self._p(idx), self._p(patches)),
+             "bx_ball_group")
+        return idx, patches
+
+    def patch_features(self, patches, radius_dev, aligned):
+        t = self.torch
+        patches = self._dev(patches, t.float32)
+        radius_dev = self._dev(radius_dev, t.float64).reshape(-1)
+        K, P, _ = patches.shape
+        R = self._empty((K, 9), t.float32)
+        feat = self._empty((K, 3, 140, 16), t.float32)
+        _chk(self.lib.bx_patch_features(self.handle, self._stream(), self._p(patches), C.c_int32(K), C.c_int32(P),
+                                        self._p(radius_dev), C.c_int32(int(aligned)), self._p(R), self._p(feat)),
+             "bx_patch_features")
+        return R, feat
+
+    def desc_net(self, feat, want_x=False):
+        t = self.torch
+        feat = self._dev(feat, t.float32)
+        K = feat.shape[0]
+        desc = self._empty((K, 32), t.float32)
+        equi = self._empty((K, 140, 32), t.float32)
+        x = self._empty((K, 2, 140, 16), t.float32) if want_x else None
+        _chk(self.lib.bx_desc_net(self.handle, self._stream(), self._p(feat), C.c_int32(K), self._p(desc), self._p(equi),
+                                  self._p(x)), "bx_desc_net")
+        return desc, equi, x
+
+    def conv_layer(self, net, layer, x, out_shape):
+        t = self.torch
+        x = self._dev(x, t.float32)
+        out = self._empty(tuple(out_shape), t.float32)
+        _chk(self.lib.bx_conv_layer(self.handle, self._stream(), C.c_int32(net), C.c_int32(layer), self._p(x),
+                                    C.c_int32(x.shape[0]), self._p(out)), "bx_conv_layer")
+        return out
+
+    def mutual(self, src_des, tgt_des):
+        t = self.torch
+        s, g = self._dev(src_des, t.float32), self._dev(tgt_des, t.float32)
+        sm = self._empty((s.shape[0],), t.int32)
+        tm = self._empty((s.shape[0],), t.int32)
+        cnt = self._empty((1,), t.int32)
+        _chk(self.lib.bx_mutual(self.handle, self._stream(), self._p(s), C.c_int32(s.shape[0]), self._p(g),
+                                C.c_int32(g.shape[0]), self._p(sm), self._p(tm), self._p(cnt)), "bx_mutual")
+        return sm, tm, cnt
+
+    def pose_net(self, s_equi, t_equi, s_mids, t_mids, m_dev, max_m, want_logits=False):
+        t = self.torch
+        s_equi, t_equi = self._dev(s_equi, t.float32), self._dev(t_equi, t.float32)
+        s_mids, t_mids, m_dev = self._dev(s_mids, t.int32), self._dev(t_mids, t.int32), self._dev(m_dev, t.int32)
+        ind = self._empty((max_m,), t.float32)
+        logits = self._empty((max_m, 2, 1, 16), t.float32) if want_logits else None
+        _chk(self.lib.bx_pose_net(self.handle, self._stream(), self._p(s_equi), self._p(t_equi), self._p(s_mids), self._p(t_mids),
+                                  self._p(m_dev), C.c_int32(max_m), self._p(ind), self._p(logits)), "bx_pose_net")
+        return ind, logits
+
+    def hypotheses(self, ind, s_mids, t_mids, m_dev, max_m, s_R, t_R, s_k, t_k):
+        t = self.torch
+        a = [self._dev(ind, t.float32), self._dev(s_mids, t.int32), self._dev(t_mids, t.int32), self._dev(m_dev, t.int32)]
+        b = [self._dev(v, t.float32) for v in (s_R, t_R, s_k, t_k)]
+        R = self._empty((max_m, 9), t.float32)
+        tt_ = self._empty((max_m, 3), t.float32)
+        ss = self._empty((max_m, 3), t.float32)
+        tg = self._empty((max_m, 3), t.float32)
+        _chk(self.lib.bx_hypotheses(self.handle, self._stream(), self._p(a[0]), self._p(a[1]), self._p(a[2]), self._p(a[3]),
+                                    C.c_int32(max_m), self._p(b[0]), self._p(b[1]), self._p(b[2]), self._p(b[3]), self._p(R),
+                                    self._p(tt_), self._p(ss), self._p(tg)), "bx_hypotheses")
+        return R, tt_, ss, tg
+
+    def consensus(self, R, tr, ss, tt, M_dev, max_M):
+        t = self.torch
+        R, tr, ss, tt = [self._dev(v, t.float32) for v in (R, tr, ss, tt)]
+        M_dev = self._dev(M_dev, t.int32)
+        inl = self._empty((max(max_M, 1),), t.int32)
+        cnt = self._empty((1,), t.int32)
+        best = self._empty((1,), t.int32)
+        _chk(self.lib.bx_consensus(self.handle, self._stream(), self._p(R), self._p(tr), self._p(ss), self._p(tt), self._p(M_dev),
+                                   C.c_int32(max_M), self._p(inl), self._p(cnt), self._p(best)), "bx_consensus")
+        return inl, cnt, best
+
+    def ransac(self, ss, tt, corr, C_dev, max_C, seed):
+        t = self.torch
+        ss, tt = self._dev(ss, t.float32), self._dev(tt, t.float32)
+        corr, C_dev = self._dev(corr, t.int32), self._dev(C_dev, t.int32)
+        T = self._empty((16,), t.float64)
+        info = self._empty((2,), t.int32)
+        _chk(self.lib.bx_ransac(self.handle, self._stream(), self._p(ss), self._p(tt), self._p(corr), self._p(C_dev),
+                                C.c_int32(max_C), C.c_uint64(seed & (2**64 - 1)), self._p(T), self._p(info)), "bx_ransac")
+        return T, info
+
+    def refine(self, ss, tt, M_dev, max_M, T):
+        t = self.torch
+        ss, tt = self._dev(ss, t.float32), self._dev(tt, t.float32)
+        M_dev = self._dev(M_dev, t.int32)
+        T = self._dev(T, t.float32).reshape(16).clone()
+        it = self._empty((1,), t.int32)
+        _chk(self.lib.bx_refine(self.handle, self._stream(), self._p(ss), self._p(tt), self._p(M_dev), C.c_int32(max_M),
+                                self._p(T), self._p(it)), "bx_refine")
+        return T, it
+
+    # ---------------------------------------------------------------- whole pair (async)
+    def register_pair_async(self, src, tgt, aligned_z, perm_src, perm_tgt, seed, result=None):
+        """Enqueue one pair on the current stream.  Returns the BxResult (valid after stream sync)."""
+        t = self.torch
+        src, tgt = self._dev(src, t.float32), self._dev(tgt, t.float32)
+        perm_src, perm_tgt = self._dev(perm_src, t.int32), self._dev(perm_tgt, t.int32)
+        res = result if result is not None else BxResult()
+        _chk(self.lib.bx_register_pair(self.handle, self._stream(), self._p(src), C.c_int32(src.shape[0]), self._p(tgt),
+                                       C.c_int32(tgt.shape[0]), C.c_int32(int(aligned_z)), self._p(perm_src), self._p(perm_tgt),
+                                       C.c_uint64(seed & (2**64 - 1)), C.byref(res)), "bx_register_pair")
+        self._keep = [src, tgt, perm_src, perm_tgt, res]
+        return res
+
+    def register_pair(self, src, tgt, aligned_z, perm_src, perm_tgt, seed):
+        res = self.register_pair_async(src, tgt, aligned_z, perm_src, perm_tgt, seed)
+        self.torch.cuda.current_stream(self.device).synchronize()
+        if res.status != 0:
+            raise BxError(f"device-side failure bits 0x{res.status:x}")
+        return res

@@ -1,0 +1,191 @@
+/*
+ * include/bufferx.h -- C-ABI of libbufferx_hip.so: the MI355X-native BUFFER-X inference hot path.
+ *
+ * This is the drop-in boundary.  Every entry point is `extern "C"`, takes plain
+ * pointers / sizes (no torch types), returns an int status (0 = BX_OK) and never throws or aborts.
+ * Device pointers are caller-owned HIP device allocations (e.g. torch tensor .data_ptr()); `stream`
+ * is a hipStream_t passed as void* (NULL = default stream).  All work is stream-ordered; no entry
+ * point synchronises the device except bx_create/bx_destroy/bx_load_weights and the *_host helpers.
+ *
+ * Each entry point replaces an operator the reference reaches through un-vendored CUDA packages or
+ * torch (reference file:line in the comment above it).  The reference binds those through Python
+ * C-extensions; the binding a maintainer would add is the ctypes stub in buffer-x_amd/lib.py
+ * (see INTEGRATION.md).
+ *
+ * Arithmetic contract: see oracle/bx_oracle.c header -- fp32 (fp64 for RANSAC), no implicit FMA
+ * contraction, documented accumulation orders, deterministic transcendentals.  Randomness that the
+ * reference leaves to unseeded global RNGs (models/patch_embedder.py:96 permutation, Open3D RANSAC
+ * sampling, models/BUFFERX.py:665 subsample) is explicit here: permutations and a 64-bit seed are inputs.
+ *
+ * Layouts:
+ *   clouds / keypoints          float32 [N][3]
+ *   patches                     float32 [K][P][3]
+ *   chunked feature maps        float32 [unit][C/16][pos][16]  (channel c of chunk at slot 4*(c%4)+c/4;
+ *                               bx_chunk_slot() below -- the order MFMA f32 16x16x4 consumes 4 k-steps
+ *                               from one 128-bit LDS read)
+ *   descriptors                 float32 [K][32];   equivariant maps float32 [K][ele*azi][32]
+ *   rotations                   float32 [.][9] row-major;  poses double/float [16] row-major 4x4
+ */
+#ifndef BUFFERX_H
+#define BUFFERX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BX_OK 0
+#define BX_ERR_ARG 1       /* bad argument */
+#define BX_ERR_HIP 2       /* HIP runtime error (bx_last_error has the string) */
+#define BX_ERR_STATE 3     /* weights not loaded, workspace too small, ... */
+#define BX_ERR_DEVICE 4    /* device-side failure flag (spin timeout, ...) */
+
+#define BX_MAX_SCALES 8
+
+typedef struct bx_ctx bx_ctx;
+
+/* Hot-path knobs == reference cfg.patch / cfg.match / cfg.test fields (config/indoor_config.py:49-80,
+ * config/outdoor_config.py:49-82; CLI overrides utils/test_args.py:46-63). */
+typedef struct bx_params {
+    int32_t num_fps;                      /* cfg.patch.num_fps */
+    int32_t num_points_per_patch;         /* cfg.patch.num_points_per_patch */
+    int32_t num_scales;                   /* cfg.patch.num_scales */
+    int32_t rad_n, azi_n, ele_n;          /* 3, 20, 7 (only these are supported by the conv kernels) */
+    int32_t voxel_sample;                 /* 10 */
+    int32_t num_points_radius_estimate;   /* 2000 */
+    double delta;                         /* 0.8 */
+    double search_radius_thresholds[BX_MAX_SCALES];
+    double dist_th, inlier_th, similar_th; /* cfg.match.* (Python floats in the reference => binary64 here) */
+    double confidence;                    /* cfg.match.confidence */
+    int32_t iter_n;                       /* cfg.match.iter_n */
+    int32_t enable_early_exit;            /* cfg.match.enable_early_exit */
+    int32_t early_exit_min_inliers;       /* cfg.match.early_exit_min_inliers */
+    int32_t pose_refine;                  /* cfg.test.pose_refine */
+    int32_t max_points;                   /* workspace sizing: largest cloud this context will see */
+} bx_params;
+
+/* BatchNorm-folded weights in kernel layout, HOST pointers (buffer-x_amd/weights.py: fold_and_pack).
+ * Replaces test.py:86-94 load_state_dict + the nn.Conv/BatchNorm modules of models/patch_embedder.py:26-41
+ * and models/patchnet.py:68-84,192-210.  Conv weights: [cin/16][taps][16][cout], bias [cout]. */
+typedef struct bx_weights {
+    const float *pnt_w;    /* [16][3] */
+    const float *pnt_b;    /* [16]    */
+    const float *pool_w1;  /* [16][32] */
+    const float *pool_b1;  /* [16] */
+    const float *pool_w2;  /* [16] */
+    const float *pool_b2;  /* [1] */
+    const float *desc_w[8];
+    const float *desc_b[8];
+    const float *pose_w[10];
+    const float *pose_b[10];
+} bx_weights;
+
+/* Result record of one registered pair == return tuple of BufferX.forward (models/BUFFERX.py:466-467)
+ * and the per-pair payload of the multi-GPU all-gather. */
+typedef struct bx_result {
+    double pose[16];          /* src -> tgt, row-major 4x4 (float32 values widened when pose_refine) */
+    int32_t num_inliers;      /* len(result.correspondence_set) of the RANSAC call */
+    int32_t num_mutual;       /* accumulated mutual matches  */
+    int32_t num_inlier_ind;   /* |inlier_ind| of the last consensus step */
+    int32_t scales_used;
+    int32_t ransac_iters;     /* iterations visited by the last RANSAC call */
+    int32_t refine_iters;
+    int32_t status;           /* 0 ok; device-side error bits otherwise */
+    int32_t reserved;
+    float des_r[BX_MAX_SCALES];
+} bx_result;
+
+/* channel c (0..15) of a 16-chunk lives in slot 4*(c%4) + c/4 */
+static inline int bx_chunk_slot(int c) { return 4 * (c & 3) + (c >> 2); }
+
+/* ---- lifecycle ------------------------------------------------------------------------------- */
+int bx_create(int device_id, const bx_params *params, bx_ctx **out);
+int bx_destroy(bx_ctx *ctx);
+const char *bx_last_error(void);
+int bx_load_weights(bx_ctx *ctx, const bx_weights *w);
+/* bytes of the per-context workspace arena (for DESIGN.md / capacity planning) */
+int64_t bx_workspace_bytes(const bx_ctx *ctx);
+
+/* ---- whole pair: replaces BufferX.forward's inference branch, models/BUFFERX.py:257-467 -------
+ * src/tgt: device float32 [n][3].  perm_src/perm_tgt: device int32 permutations, one per scale
+ * ([num_scales][n], stands in for np.random.choice at models/patch_embedder.py:96).  seed drives the
+ * RANSAC sampling (and the >200k subsample).  result: HOST pointer (pinned memory recommended),
+ * valid after the stream is synchronised.                                                      */
+int bx_register_pair(bx_ctx *ctx, void *stream, const float *src, int32_t n_src, const float *tgt, int32_t n_tgt,
+                     int32_t aligned_z, const int32_t *perm_src, const int32_t *perm_tgt, uint64_t seed,
+                     bx_result *result);
+
+/* ---- stage entry points (parity tests + operator-level drop-ins) ----------------------------- */
+
+/* pointnet2_ops.furthest_point_sample + gather_operation (models/BUFFERX.py:286-290,338-346).
+ * idx_out int32 [m]; kpts_out float32 [m][3] (nullable). */
+int bx_fps(bx_ctx *ctx, void *stream, const float *xyz, int32_t n, int32_t m, int32_t *idx_out, float *kpts_out);
+
+/* density_aware_radius_estimation (models/BUFFERX.py:627-696) for `nthr` thresholds.
+ * pts float32 [n_pts][3] (already subsampled if n_orig > 200000), kpts [nk][3].
+ * des_r_out: device double [nthr].                                                              */
+int bx_radius(bx_ctx *ctx, void *stream, const float *pts, int32_t n_pts, int64_t n_orig, const float *kpts,
+              int32_t nk, const double *thresholds_host, int32_t nthr, double *des_r_out);
+
+/* out[i] = pts[perm[i]]  (models/patch_embedder.py:96-97) */
+int bx_permute(bx_ctx *ctx, void *stream, const float *pts, const int32_t *perm, int32_t n, float *out);
+
+/* MiniSpinNet.select_patches: ball_query + grouping_operation + mask arithmetic
+ * (models/patch_embedder.py:92-120).  pts_perm [n][3] already permuted; radius: device double (as
+ * produced by bx_radius).  idx_out int32 [K][P] (nullable), patches_out float32 [K][P][3].       */
+int bx_ball_group(bx_ctx *ctx, void *stream, const float *pts_perm, int32_t n, const float *kpts, int32_t K,
+                  const double *radius, int32_t P, int32_t *idx_out, float *patches_out);
+
+/* axis_align + normalize + SPT + pnt_layer + max-pool (models/patch_embedder.py:122-170, 26-30, 73-77;
+ * utils/common.py:431-498, 501-525, 709-726).  R_out float32 [K][9]; feat_out chunked [K][rad_n][ele*azi][16]. */
+int bx_patch_features(bx_ctx *ctx, void *stream, const float *patches, int32_t K, int32_t P, const double *radius,
+                      int32_t aligned_z, float *R_out, float *feat_out);
+
+/* Cylindrical_Net conv stack + pool_layer + weighted pooling + norms
+ * (models/patchnet.py:49-84, models/patch_embedder.py:78-83).  feat chunked [K][3][140][16];
+ * desc_out [K][32]; equi_out [K][140][32].  x_out (nullable): last conv output, chunked [K][2][140][16]. */
+int bx_desc_net(bx_ctx *ctx, void *stream, const float *feat, int32_t K, float *desc_out, float *equi_out, float *x_out);
+
+/* one convolution layer of either stack (parity of the MFMA kernel): net 0 = Desc (layers 0..7),
+ * net 1 = Pose (layers 1..9; layer 0 consumes the implicit cost volume, see bx_pose_net).
+ * in/out chunked layout; units = patches or matches.                                            */
+int bx_conv_layer(bx_ctx *ctx, void *stream, int32_t net, int32_t layer, const float *in, int32_t units, float *out);
+
+/* BufferX.mutual_matching (models/BUFFERX.py:469-496; knn_cuda.KNN k=1).  s_mids/t_mids int32 [ns],
+ * count_out device int32 [1]. */
+int bx_mutual(bx_ctx *ctx, void *stream, const float *src_des, int32_t ns, const float *tgt_des, int32_t nt,
+              int32_t *s_mids, int32_t *t_mids, int32_t *count_out);
+
+/* CostVolume.forward (models/BUFFERX.py:51-69) incl. CostNet (models/patchnet.py:192-210), softmax and
+ * soft-argmax.  m_dev: device int32 count of matches (<= max_m).  ind_out float32 [max_m].
+ * logits_out (nullable) float32 chunked [max_m][2][1][16].                                      */
+int bx_pose_net(bx_ctx *ctx, void *stream, const float *s_equi, const float *t_equi, const int32_t *s_mids,
+                const int32_t *t_mids, const int32_t *m_dev, int32_t max_m, float *ind_out, float *logits_out);
+
+/* hypothesis recovery (models/BUFFERX.py:382-389; kornia axis_angle_to_rotation_matrix).
+ * s_R/t_R [K][9], kpts [K][3] indexed through s_mids/t_mids; writes R_out [m][9], t_out [m][3],
+ * ss_out/tt_out [m][3] (matched keypoints).                                                     */
+int bx_hypotheses(bx_ctx *ctx, void *stream, const float *ind, const int32_t *s_mids, const int32_t *t_mids,
+                  const int32_t *m_dev, int32_t max_m, const float *s_R, const float *t_R, const float *s_kpts,
+                  const float *t_kpts, float *R_out, float *t_out, float *ss_out, float *tt_out);
+
+/* cross-scale consensus maximisation (models/BUFFERX.py:405-417).  M_dev: device count.
+ * inlier_out int32 [max_M], count_out device int32 [1], best_out device int32 [1] (nullable).    */
+int bx_consensus(bx_ctx *ctx, void *stream, const float *R, const float *t, const float *ss, const float *tt,
+                 const int32_t *M_dev, int32_t max_M, int32_t *inlier_out, int32_t *count_out, int32_t *best_out);
+
+/* PoseEstimator._estimate_ransac (models/pose_estimator.py:84-117; Open3D 0.18
+ * registration_ransac_based_on_correspondence), seeded.  corr int32 [C_dev]; T_out device double [16];
+ * info_out device int32 [2] = {num_inliers, iterations visited}.                                */
+int bx_ransac(bx_ctx *ctx, void *stream, const float *ss, const float *tt, const int32_t *corr, const int32_t *C_dev,
+              int32_t max_C, uint64_t seed, double *T_out, int32_t *info_out);
+
+/* BufferX.post_refinement + rigid_transform_3d (models/BUFFERX.py:522-603).  T_io device float [16];
+ * iters_out device int32 [1] (nullable).                                                        */
+int bx_refine(bx_ctx *ctx, void *stream, const float *ss, const float *tt, const int32_t *M_dev, int32_t max_M,
+              float *T_io, int32_t *iters_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BUFFERX_H */

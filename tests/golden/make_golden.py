@@ -25,10 +25,10 @@ CASES = {
     "indoor_success": ("3DMatch", "indoor_identical", 5000, 3,
                        dict(num_fps=256, num_points_per_patch=128, num_scales=2, search_radius_thresholds=[2, 1],
                             num_points_radius_estimate=256, iter_n=4000)),
-    "indoor_early": ("3DMatch", "indoor_identical", 4000, 4,
-                     dict(num_fps=192, num_points_per_patch=96, num_scales=2, search_radius_thresholds=[2, 1],
-                          num_points_radius_estimate=192, iter_n=4000, enable_early_exit=True,
-                          early_exit_min_inliers=4)),
+    "indoor_early": ("3DMatch", "indoor_identical", 5000, 3,
+                     dict(num_fps=256, num_points_per_patch=128, num_scales=2, search_radius_thresholds=[2, 1],
+                          num_points_radius_estimate=256, iter_n=4000, enable_early_exit=True,
+                          early_exit_min_inliers=10)),
     "outdoor_small": ("KITTI", "outdoor", 0, 5,
                       dict(num_fps=80, num_points_per_patch=64, num_scales=1, search_radius_thresholds=[2],
                            num_points_radius_estimate=200, iter_n=1200)),
@@ -68,6 +68,7 @@ def run_reference(name):
     cap = {}
     src, tgt = pair["src"], pair["tgt"]
     S = cfg.patch.num_scales
+    del rh.PERM_QUEUE[:]
     for i in range(S):
         rh.PERM_QUEUE.append(rh.make_perm(len(src), seed, 2 * i))
         rh.PERM_QUEUE.append(rh.make_perm(len(tgt), seed, 2 * i + 1))

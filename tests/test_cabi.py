@@ -1,0 +1,61 @@
+"""The C-ABI shared library loads and exports every symbol include/bufferx.h declares (no compute: CPU-only)."""
+import ctypes as C
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "bufferx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"^\s*(?:int|int64_t|const char \*|void)\s*\*?\s*(bx_[a-z0-9_]+)\s*\(", src, flags=re.M)
+    return sorted(set(n for n in names if n != "bx_chunk_slot"))
+
+
+def test_header_symbols_exported():
+    from bufferx_amd import lib
+    lib.build()
+    so = C.CDLL(lib._SO)
+    decl = _declared()
+    assert len(decl) >= 19, decl
+    for name in decl:
+        assert hasattr(so, name), f"{name} declared in include/bufferx.h but not exported"
+    assert sorted(lib.EXPORTS) == decl
+
+
+def test_struct_layouts_match_header():
+    from bufferx_amd import lib
+    # bx_params: 8 int32, 1+8+3+1 doubles, 5 int32 (+pad) ; bx_result: 16 doubles + 8 int32 + 8 floats
+    assert C.sizeof(lib.BxParams) == 8 * 4 + 13 * 8 + 5 * 4 + 4
+    assert C.sizeof(lib.BxResult) == 16 * 8 + 8 * 4 + 8 * 4
+    assert lib.BxParams.delta.offset == 32 and lib.BxParams.confidence.offset == 32 + 8 * 12
+
+
+def test_error_path_without_gpu():
+    """bx_create on a box without a GPU must return an error code and a message, never abort."""
+    import torch
+    from bufferx_amd import lib
+    import bufferx_amd
+    if torch.cuda.is_available():
+        return
+    so = lib.load()
+    p = lib.params_from_cfg(bufferx_amd.make_cfg("3DMatch"), 1000)
+    h = C.c_void_p()
+    rc = so.bx_create(0, C.byref(p), C.byref(h))
+    assert rc != 0 and len(so.bx_last_error()) > 0
+    p.rad_n = 4
+    assert so.bx_create(0, C.byref(p), C.byref(h)) == 1  # BX_ERR_ARG: geometry other than 3/7/20 is rejected
+
+
+def test_slot_permutation_is_involution_free_bijection():
+    import numpy as np
+    from bufferx_amd import lib
+    inv = lib.slot_perm()
+    assert sorted(inv.tolist()) == list(range(16))
+    x = np.arange(32, dtype=np.float32).reshape(2, 16)
+    assert np.array_equal(lib.chunked_to_logical(lib.logical_to_chunked(x)), x)
+    # slot 4*(c%4)+c/4 holds channel c
+    ch = lib.logical_to_chunked(np.arange(16, dtype=np.float32)[None])[0]
+    for c in range(16):
+        assert ch[4 * (c % 4) + c // 4] == c

@@ -1,0 +1,83 @@
+"""GPU end-to-end parity: bx_register_pair (C-ABI) vs the oracle pipeline and vs the committed golden fixtures
+minted from the real reference code (tests/golden/make_golden.py)."""
+import os
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "indoor_small": ("3DMatch", "indoor", 3500, 11, False,
+                     dict(num_fps=96, num_points_per_patch=96, num_scales=2, search_radius_thresholds=[5, 2],
+                          num_points_radius_estimate=256), dict(iter_n=4000)),
+    "indoor_success": ("3DMatch", "indoor", 5000, 3, True,
+                       dict(num_fps=256, num_points_per_patch=128, num_scales=2, search_radius_thresholds=[2, 1],
+                            num_points_radius_estimate=256), dict(iter_n=4000)),
+    "indoor_early": ("3DMatch", "indoor", 5000, 3, True,
+                     dict(num_fps=256, num_points_per_patch=128, num_scales=2, search_radius_thresholds=[2, 1],
+                          num_points_radius_estimate=256), dict(iter_n=4000, enable_early_exit=True, early_exit_min_inliers=10)),
+    "outdoor_small": ("KITTI", "outdoor", 0, 5, False,
+                      dict(num_fps=80, num_points_per_patch=64, num_scales=1, search_radius_thresholds=[2],
+                           num_points_radius_estimate=200), dict(iter_n=1200)),
+}
+
+
+def make_case(bx, name):
+    ds, kind, n, seed, identical, patch_ov, match_ov = CASES[name]
+    cfg = bx.make_cfg(ds)
+    for k, v in patch_ov.items():
+        cfg.patch[k] = v
+    for k, v in match_ov.items():
+        cfg.match[k] = v
+    if kind == "indoor":
+        pair = bx.synth.make_pair(seed, "indoor", n_target=n, identical=identical)
+    else:
+        pair = bx.synth.make_pair(seed, "outdoor", voxel=0.6)
+    return cfg, pair, seed
+
+
+def run_gpu(bx, packed, oracle, cfg, pair, seed):
+    from bufferx_amd import lib
+    ctx = lib.Context(cfg, max_points=max(len(pair["src"]), len(pair["tgt"])), device=0, packed_weights=packed)
+    S = cfg.patch.num_scales
+    perm_s = np.stack([oracle.make_perm(len(pair["src"]), seed, 2 * i) for i in range(S)])
+    perm_t = np.stack([oracle.make_perm(len(pair["tgt"]), seed, 2 * i + 1) for i in range(S)])
+    res = ctx.register_pair(pair["src"], pair["tgt"], pair["aligned_z"], perm_s, perm_t, seed)
+    out = (np.array(res.pose).reshape(4, 4), res.num_inliers, res.num_mutual, res.num_inlier_ind, res.scales_used,
+           [res.des_r[i] for i in range(S)])
+    ctx.close()
+    return out
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_pair_matches_oracle_and_golden(bx, packed, oracle, golden_dir, name):
+    from oracle import pipeline as PL
+    cfg, pair, seed = make_case(bx, name)
+    pose, n_inl, n_mut, n_ind, scales, des_r = run_gpu(bx, packed, oracle, cfg, pair, seed)
+    ref = PL.register_pair(pair["src"], pair["tgt"], packed, cfg, pair["aligned_z"], seed)
+    # bit-exact against the oracle (same arithmetic contract)
+    assert (n_inl, n_mut, n_ind, scales) == tuple(ref[1:])
+    assert np.array_equal(pose, np.asarray(ref[0], np.float64))
+    # and within tolerance of the REAL reference code's output (golden fixture)
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    assert np.array_equal(pair["src"][:8], g["src_head"]) and np.array_equal(pair["tgt"][:8], g["tgt_head"])
+    assert (n_inl, n_mut, n_ind, scales) == (int(g["num_inliers"]), int(g["num_mutual"]), int(g["num_inlier_ind"]), int(g["scales_used"]))
+    assert np.allclose(des_r[:scales], g["des_r"][:scales], atol=1e-6)
+    # north_star tolerance: 1e-4 deg / 1e-4 m
+    rre, rte = bx.synth.pose_error(pose, g["pose"])
+    assert rre < 1e-4 and rte < 1e-4
+
+
+def test_pair_larger_config_success(bx, packed, oracle):
+    """K=1024, P=256, 2 scales on a 12k-point noisy partial-overlap pair: registration must succeed and agree
+    with the oracle bit for bit."""
+    from oracle import pipeline as PL
+    cfg = bx.make_cfg("3DMatch")
+    cfg.patch.num_fps, cfg.patch.num_points_per_patch, cfg.patch.num_scales = 1024, 256, 2
+    cfg.patch.search_radius_thresholds = [5, 2]
+    cfg.patch.num_points_radius_estimate = 512
+    pair = bx.synth.make_pair(21, "indoor", n_target=12000, overlap=0.8)
+    pose, n_inl, n_mut, n_ind, scales, _ = run_gpu(bx, packed, oracle, cfg, pair, 9)
+    ref = PL.register_pair(pair["src"], pair["tgt"], packed, cfg, pair["aligned_z"], 9)
+    assert (n_inl, n_mut, n_ind, scales) == tuple(ref[1:])
+    assert np.array_equal(pose, np.asarray(ref[0], np.float64))

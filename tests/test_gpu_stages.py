@@ -1,0 +1,280 @@
+"""GPU parity tests: every stage of the HIP hot path, called through the C-ABI (include/bufferx.h), against the
+CPU oracle on the same seeded inputs.  Index / integer outputs must be bit-exact; fp32/fp64 outputs are
+bit-exact by the arithmetic contract (see oracle/bx_oracle.c) -- asserted with zero tolerance where the
+contract covers the whole stage."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(bx, K=128, P=96, S=1, nk=128, ds="3DMatch", **kw):
+    cfg = bx.make_cfg(ds)
+    cfg.patch.num_fps, cfg.patch.num_points_per_patch, cfg.patch.num_scales = K, P, S
+    cfg.patch.search_radius_thresholds = [5, 2, 0.5][:S]
+    cfg.patch.num_points_radius_estimate = nk
+    for k, v in kw.items():
+        cfg.match[k] = v
+    return cfg
+
+
+@pytest.fixture(scope="module")
+def ctx(bx, packed):
+    from bufferx_amd import lib
+    c = lib.Context(_cfg(bx, K=256, P=128, S=2, nk=256), max_points=70000, device=0, packed_weights=packed)
+    yield c
+    c.close()
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------ FPS (row 2/3)
+@pytest.mark.parametrize("n,m", [(700, 64), (3000, 256), (9000, 256), (20000, 200), (40000, 160), (66000, 96)])
+def test_fps_exact(ctx, oracle, n, m):
+    rng = np.random.default_rng(n)
+    xyz = (rng.random((n, 3), np.float32) * 4 - 1).astype(np.float32)
+    idx, kp = ctx.fps(xyz, m)
+    ref = oracle.fps(xyz, m)
+    assert np.array_equal(_np(idx), ref)
+    assert np.array_equal(_np(kp), xyz[ref])
+
+
+def test_fps_ties_and_origin_skip(ctx, oracle):
+    # integer lattice => many exact distance ties (tie rule: lower k mod 512, then lower k);
+    # points within 1e-3 of the origin are never candidates (upstream `continue`)
+    g = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(8), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    g = g * 0.25
+    g[5] = [0.01, 0.0, 0.0]
+    rng = np.random.default_rng(0)
+    g = g[rng.permutation(len(g))]
+    idx, _ = ctx.fps(g, 200)
+    assert np.array_equal(_np(idx), oracle.fps(g, 200))
+
+
+# ------------------------------------------------------------------ radius estimation (row 1)
+def test_radius(ctx, oracle, bx):
+    pair = bx.synth.make_pair(1, "indoor", n_target=6000)
+    pts = pair["src"]
+    kp = pts[oracle.fps(pts, 256)]
+    thr = [5, 2, 0.5]
+    got = _np(ctx.radius(pts, len(pts), kp, thr))
+    ref = [oracle.radius(pts, len(pts), kp, t) for t in thr]
+    assert np.array_equal(got, np.array(ref))
+
+
+# ------------------------------------------------------------------ neighbour gather (row 4)
+@pytest.mark.parametrize("n,K,P,r", [(5000, 200, 64, 0.35), (5000, 200, 128, 0.2), (30000, 256, 128, 0.12), (2500, 100, 96, 2.0)])
+def test_ball_group_exact(ctx, oracle, bx, n, K, P, r):
+    import torch
+    pair = bx.synth.make_pair(n, "indoor", n_target=n)
+    pts = pair["src"]
+    perm = oracle.make_perm(len(pts), 5, 0)
+    pp = _np(ctx.permute(pts, perm))
+    assert np.array_equal(pp, pts[perm])
+    kp = pts[oracle.fps(pts, K)]
+    rad = torch.tensor([r], dtype=torch.float64)
+    idx, patches = ctx.ball_group(pp, kp, rad, P)
+    ridx, rpatches = oracle.ball_group(pp, kp, np.float32(r), P)
+    assert np.array_equal(_np(idx), ridx)
+    assert np.array_equal(_np(patches), rpatches)
+
+
+def test_ball_group_no_hits(ctx, oracle):
+    import torch
+    rng = np.random.default_rng(1)
+    pts = rng.random((1000, 3), np.float32)
+    kp = (rng.random((16, 3), np.float32) + 10).astype(np.float32)   # far away: no hit -> idx 0 everywhere
+    idx, patches = ctx.ball_group(pts, kp, torch.tensor([0.1], dtype=torch.float64), 32)
+    ridx, rp = oracle.ball_group(pts, kp, np.float32(0.1), 32)
+    assert np.array_equal(_np(idx), ridx) and np.array_equal(_np(patches), rp)
+
+
+# ------------------------------------------------------------------ patch features (rows 5-8)
+@pytest.mark.parametrize("aligned", [False, True])
+def test_patch_features(ctx, oracle, bx, packed, aligned):
+    import torch
+    from bufferx_amd import lib
+    pair = bx.synth.make_pair(2, "indoor", n_target=5000)
+    pts = pair["src"]
+    kp = pts[oracle.fps(pts, 96)]
+    r = 0.3
+    _, patches = oracle.ball_group(pts, kp, np.float32(r), 128)
+    R, feat = ctx.patch_features(patches, torch.tensor([r], dtype=torch.float64), aligned)
+    rR, rfeat = oracle.patch_features(patches, r, aligned, packed["pnt_w"], packed["pnt_b"])
+    assert np.array_equal(_np(R), rR)
+    got = lib.chunked_to_logical(_np(feat))
+    assert np.array_equal(got, rfeat)
+
+
+# ------------------------------------------------------------------ convolution layers (rows 9, 12)
+@pytest.mark.parametrize("layer", range(8))
+def test_desc_conv_layer_exact(ctx, oracle, bx, packed, layer):
+    from bufferx_amd import lib
+    L = packed["desc"][layer]
+    nch = L["W"].shape[0]
+    rng = np.random.default_rng(layer)
+    units = 11   # not a multiple of the units-per-workgroup: exercises the tail
+    x = rng.standard_normal((units, nch, 140, 16)).astype(np.float32)
+    x[rng.random(x.shape) < 0.3] = 0
+    ref = oracle.conv(x, bx.weights.cyl_tap_table(), L["W"], L["b"], L["relu"])
+    out = ctx.conv_layer(0, layer, lib.logical_to_chunked(x), ref.shape)
+    assert np.array_equal(lib.chunked_to_logical(_np(out)), ref)
+
+
+@pytest.mark.parametrize("layer", range(1, 10))
+def test_pose_conv_layer_exact(ctx, oracle, bx, packed, layer):
+    from bufferx_amd import lib
+    L = packed["pose"][layer]
+    dims, k, _ = bx.weights.pose_geometry()[layer]
+    tap, od = bx.weights.valid_tap_table(dims, k)
+    nch = L["W"].shape[0]
+    rng = np.random.default_rng(100 + layer)
+    units = 37 if layer >= 5 else 5
+    x = rng.standard_normal((units, nch, int(np.prod(dims)), 16)).astype(np.float32)
+    ref = oracle.conv(x, tap, L["W"], L["b"], L["relu"])
+    out = ctx.conv_layer(1, layer, lib.logical_to_chunked(x), ref.shape)
+    assert np.array_equal(lib.chunked_to_logical(_np(out)), ref)
+
+
+def test_desc_net(ctx, oracle, bx, packed):
+    from bufferx_amd import lib
+    rng = np.random.default_rng(3)
+    K = 37
+    feat = np.abs(rng.standard_normal((K, 3, 140, 16))).astype(np.float32)
+    x = feat
+    for L in packed["desc"]:
+        x = oracle.conv(x, bx.weights.cyl_tap_table(), L["W"], L["b"], L["relu"])
+    rdesc, requi = oracle.desc_head(x, packed["pool_w1"], packed["pool_b1"], packed["pool_w2"], packed["pool_b2"])
+    desc, equi, xo = ctx.desc_net(lib.logical_to_chunked(feat), want_x=True)
+    assert np.array_equal(lib.chunked_to_logical(_np(xo)), x)
+    assert np.array_equal(_np(desc), rdesc)
+    assert np.array_equal(_np(equi), requi)
+
+
+# ------------------------------------------------------------------ matching (row 11)
+def test_mutual(ctx, oracle):
+    rng = np.random.default_rng(4)
+    a = rng.standard_normal((250, 32)).astype(np.float32)
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b = a[rng.permutation(250)][:230] + 0.05 * rng.standard_normal((230, 32)).astype(np.float32)
+    b[7] = b[3]  # exact duplicate -> tie broken by lowest index
+    sm, tm, cnt = ctx.mutual(a, b.astype(np.float32))
+    rs, rt, _, _ = oracle.mutual(a, b)
+    m = int(_np(cnt)[0])
+    assert m == len(rs)
+    assert np.array_equal(_np(sm)[:m], rs) and np.array_equal(_np(tm)[:m], rt)
+
+
+# ------------------------------------------------------------------ CostNet + soft-argmax (row 12)
+def test_pose_net(ctx, oracle, bx, packed):
+    import torch
+    rng = np.random.default_rng(5)
+    K = 40
+    se = rng.standard_normal((K, 140, 32)).astype(np.float32)
+    te = rng.standard_normal((K, 140, 32)).astype(np.float32)
+    se /= np.linalg.norm(se, axis=2, keepdims=True)
+    te /= np.linalg.norm(te, axis=2, keepdims=True)
+    m = 23
+    sm = rng.permutation(K)[:m].astype(np.int32)
+    tm = rng.permutation(K)[:m].astype(np.int32)
+    x = oracle.cost_volume(se, te, sm, tm)
+    for L, (dims, k, _) in zip(packed["pose"], bx.weights.pose_geometry()):
+        tap, _ = bx.weights.valid_tap_table(dims, k)
+        x = oracle.conv(x, tap, L["W"], L["b"], L["relu"])
+    rind = oracle.soft_argmax(x)
+    smp = np.zeros(K, np.int32); smp[:m] = sm
+    tmp = np.zeros(K, np.int32); tmp[:m] = tm
+    from bufferx_amd import lib
+    ind, logits = ctx.pose_net(se, te, smp, tmp, torch.tensor([m], dtype=torch.int32), K, want_logits=True)
+    assert np.array_equal(lib.chunked_to_logical(_np(logits))[:m], x)
+    assert np.array_equal(_np(ind)[:m], rind)
+
+
+# ------------------------------------------------------------------ hypotheses + consensus (row 13)
+def _random_rot(rng, n):
+    q = rng.standard_normal((n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q.T
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                  2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                  2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1)
+    return R.astype(np.float32)
+
+
+def test_hypotheses_and_consensus(ctx, oracle):
+    import torch
+    rng = np.random.default_rng(6)
+    K, m = 200, 150
+    sR, tR = _random_rot(rng, K), _random_rot(rng, K)
+    sk = (rng.random((K, 3)) * 3).astype(np.float32)
+    tk = (rng.random((K, 3)) * 3).astype(np.float32)
+    sm = rng.permutation(K)[:m].astype(np.int32)
+    tm = rng.permutation(K)[:m].astype(np.int32)
+    ind = (rng.random(m) * 19).astype(np.float32)
+    ind[0] = 0.0          # exercises kornia's small-angle branch (angle^2 <= 1e-6)
+    ind[1] = 1e-4
+    rR, rt = oracle.hypotheses(ind, sR[sm], tR[tm], sk[sm], tk[tm])
+    smp = np.zeros(K, np.int32); smp[:m] = sm
+    tmp = np.zeros(K, np.int32); tmp[:m] = tm
+    indp = np.zeros(K, np.float32); indp[:m] = ind
+    R, t, ss, tt = ctx.hypotheses(indp, smp, tmp, torch.tensor([m], dtype=torch.int32), K, sR, tR, sk, tk)
+    assert np.array_equal(_np(R)[:m], rR) and np.array_equal(_np(t)[:m], rt)
+    assert np.array_equal(_np(ss)[:m], sk[sm]) and np.array_equal(_np(tt)[:m], tk[tm])
+    # consensus on a planted model: 60% of the matches follow one rigid motion
+    Rg = _random_rot(rng, 1)[0].reshape(3, 3)
+    tg = np.array([0.3, -0.2, 0.5], np.float32)
+    M = 300
+    s = (rng.random((M, 3)) * 4 + 1).astype(np.float32)
+    g = (s @ Rg.T + tg).astype(np.float32)
+    out = rng.random(M) < 0.4
+    g[out] += rng.standard_normal((int(out.sum()), 3)).astype(np.float32)
+    Rh = np.tile(Rg.reshape(1, 9), (M, 1)).astype(np.float32)
+    Rh[out] = _random_rot(rng, int(out.sum()))
+    th = (g - np.einsum("mij,mj->mi", Rh.reshape(M, 3, 3), s)).astype(np.float32)
+    rinl, rbest, rcnt = oracle.consensus(Rh, th, s, g, 1 / 3)
+    inl, cnt, best = ctx.consensus(Rh, th, s, g, torch.tensor([M], dtype=torch.int32), 512)
+    c = int(_np(cnt)[0])
+    assert c == len(rinl) and int(_np(best)[0]) == rbest
+    assert np.array_equal(_np(inl)[:c], rinl)
+
+
+# ------------------------------------------------------------------ RANSAC + refinement (rows 14, 16)
+@pytest.mark.parametrize("conf,iters", [(0.999, 50000), (1.0, 6000)])
+def test_ransac_and_refine(bx, packed, oracle, conf, iters):
+    import torch
+    from bufferx_amd import lib
+    cfg = _cfg(bx, K=256, P=64, S=2, nk=64, confidence=conf, iter_n=iters)
+    c = lib.Context(cfg, max_points=1000, device=0, packed_weights=packed)
+    rng = np.random.default_rng(7)
+    M = 400
+    Rg = _random_rot(rng, 1)[0].reshape(3, 3).astype(np.float64)
+    tg = np.array([0.5, 0.1, -0.4])
+    s = (rng.random((M, 3)) * 3).astype(np.float32)
+    g = (s @ Rg.T + tg + 0.01 * rng.standard_normal((M, 3))).astype(np.float32)
+    bad = rng.random(M) < 0.5
+    g[bad] = (rng.random((int(bad.sum()), 3)) * 3).astype(np.float32)
+    corr = np.sort(rng.permutation(M)[:300]).astype(np.int32)
+    rT, rn, rit = oracle.ransac(s, g, corr, cfg.match.dist_th, cfg.match.similar_th, conf, iters, 1234)
+    T, info = c.ransac(s, g, corr, torch.tensor([len(corr)], dtype=torch.int32), 512, 1234)
+    info = _np(info)
+    assert info[0] == rn and info[1] == rit
+    assert np.array_equal(_np(T).reshape(4, 4), rT)
+    # refinement from the RANSAC pose
+    rTf, rits = oracle.refine(s, g, cfg.match.dist_th, rT.astype(np.float32))
+    Tf, its = c.refine(s, g, torch.tensor([M], dtype=torch.int32), 512, rT.astype(np.float32))
+    assert int(_np(its)[0]) == rits
+    assert np.array_equal(_np(Tf).reshape(4, 4), rTf)
+    c.close()
+
+
+def test_ransac_degenerate(bx, packed, oracle):
+    import torch
+    from bufferx_amd import lib
+    cfg = _cfg(bx, K=64, P=64, S=1, nk=64, iter_n=500)
+    c = lib.Context(cfg, max_points=1000, device=0, packed_weights=packed)
+    s = np.zeros((10, 3), np.float32)
+    T, info = c.ransac(s, s, np.arange(2, dtype=np.int32), torch.tensor([2], dtype=torch.int32), 64, 1)
+    assert np.array_equal(_np(T).reshape(4, 4), np.eye(4)) and _np(info)[0] == 0   # C < 3 -> identity, 0 inliers
+    c.close()

@@ -1,0 +1,82 @@
+"""Pins the CPU oracle against fixtures minted from the REAL reference code (tests/golden/make_golden.py runs
+BufferX.forward of /root/reference on CPU with numpy stubs for the un-vendored CUDA ops)."""
+import os
+import numpy as np
+import pytest
+
+from test_gpu_pipeline import CASES, make_case
+
+
+@pytest.fixture(scope="module")
+def helpers(golden_dir):
+    return np.load(os.path.join(golden_dir, "helpers.npz"))
+
+
+def test_voxel_tables_bit_exact(oracle, helpers):
+    cen, rot = oracle.voxel_table()
+    assert np.array_equal(cen, helpers["voxel_centres"])          # get_voxel_coordinate (utils/common.py:422-428)
+    R = helpers["inv_rot"]                                         # var_to_invar table (utils/common.py:483-493)
+    assert np.array_equal(rot[:, 0], R[:, 0, 0]) and np.array_equal(rot[:, 1], R[:, 0, 1])
+    assert np.array_equal(rot[:, 2], R[:, 1, 0]) and np.array_equal(rot[:, 3], R[:, 1, 1])
+    # SURVEY.md Appendix C known answers
+    assert np.allclose(cen[0], [0.03663022, 0.00580166, 0.16248799], atol=1e-8)
+    assert np.allclose(cen[419], [0.18315111, -0.02900829, -0.81243993], atol=1e-8)
+
+
+def test_radius_known_answers(oracle, helpers):
+    """density_aware_radius_estimation on torch.rand(20000,3)*4 -> 1.01 / 0.72 / 0.44."""
+    import torch
+    torch.manual_seed(0)
+    P = (torch.rand(20000, 3) * 4).numpy()
+    assert np.array_equal(P[::50], helpers["radius_kat_pts"])
+    got = [oracle.radius(P, len(P), P[:2000], t) for t in (5, 2, 0.5)]
+    assert got == helpers["radius_kat"].tolist() == [1.01, 0.72, 0.44]
+
+
+def test_axis_helpers_close_to_reference(oracle, helpers, packed):
+    # RodsRotatFormula + cal_Z_axis are exercised through bxo_patch_features: build patches whose last point
+    # is the centre and compare the returned R with the reference's for the same z axis.
+    d, ref = helpers["calz_in"], helpers["calz_ref"]
+    patches = np.concatenate([d + ref[:, None, :], ref[:, None, :]], 1).astype(np.float32)  # last slot = centre
+    R, _ = oracle.patch_features(patches, 1.0, False, packed["pnt_w"], packed["pnt_b"])
+    import torch
+    z = torch.from_numpy(helpers["calz_out"])
+    z = z / z.norm(dim=1, keepdim=True)
+    # reference R for that z (restated RodsRotatFormula output is in the fixture for random z)
+    zin, Rref = helpers["rods_in"], helpers["rods_out"]
+    assert zin.shape == (64, 3) and Rref.shape == (64, 3, 3)
+    # the oracle's R maps z -> +z axis:  z @ R == (0,0,1)
+    zz = np.einsum("ki,kij->kj", z.numpy(), R.reshape(-1, 3, 3))
+    assert np.allclose(zz, np.tile([0, 0, 1], (len(zz), 1)), atol=2e-6)
+    zr = np.einsum("ki,kij->kj", zin, Rref)
+    assert np.allclose(zr, np.tile([0, 0, 1], (64, 1)), atol=2e-6)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_pipeline_matches_reference(bx, packed, golden_dir, name):
+    from oracle import pipeline as PL
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg, pair, seed = make_case(bx, name)
+    assert np.array_equal(pair["src"][:8], g["src_head"]) and len(pair["src"]) == int(g["n_src"])
+    cap = {}
+    pose, n_inl, n_mut, n_ind, scales = PL.register_pair(pair["src"], pair["tgt"], packed, cfg, pair["aligned_z"], seed, cap)
+    assert scales == int(g["scales_used"])
+    for i in range(scales):
+        assert cap[f"s{i}_des_r"] == pytest.approx(float(g["des_r"][i]), abs=1e-12)
+        for c in ("src", "tgt"):
+            tag = f"s{i}_{c}_"
+            assert np.abs(cap[tag + "desc"] - g[tag + "desc"]).max() < 2e-5
+            assert np.abs(cap[tag + "R"].reshape(-1, 3, 3) - g[tag + "R"]).max() < 1e-5
+            equi = cap[tag + "equi"].reshape(-1, 7, 20, 32).transpose(0, 3, 1, 2)[::16]
+            assert np.abs(equi - g[tag + "equi_sub"]).max() < 1e-5
+        assert np.array_equal(cap[f"s{i}_s_mids"], g[f"s{i}_s_mids"])
+        assert np.array_equal(cap[f"s{i}_t_mids"], g[f"s{i}_t_mids"])
+        assert np.abs(cap[f"s{i}_ind"] - g[f"s{i}_ind"]).max() < 5e-5
+    k = 0
+    while f"est{k}_T" in g:
+        k += 1
+    assert np.array_equal(cap[f"s{scales - 1}_inlier_ind"], g[f"est{k - 1}_inlier_ind"])
+    assert np.abs(cap["init_pose"] - g[f"est{k - 1}_T"]).max() < 1e-9
+    assert (n_inl, n_mut, n_ind) == (int(g["num_inliers"]), int(g["num_mutual"]), int(g["num_inlier_ind"]))
+    rre, rte = bx.synth.pose_error(np.asarray(pose, np.float64), g["pose"])
+    assert rre < 1e-4 and rte < 1e-4      # north_star tolerance: 1e-4 deg / 1e-4 m

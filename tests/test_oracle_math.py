@@ -1,0 +1,96 @@
+"""Deterministic elementary functions of the oracle (oracle/bxo_detmath.h) vs numpy / LAPACK."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+SHIM = r"""
+#include "bxo_detmath.h"
+void t_exp(const double*x,int n,double*o){for(int i=0;i<n;++i)o[i]=bxo_exp(x[i]);}
+void t_sincos(const double*x,int n,double*s,double*c){for(int i=0;i<n;++i)bxo_sincos(x[i],s+i,c+i);}
+void t_acos(const double*x,int n,double*o){for(int i=0;i<n;++i)o[i]=bxo_acos(x[i]);}
+void t_log(const double*x,int n,double*o){for(int i=0;i<n;++i)o[i]=bxo_log(x[i]);}
+void t_jacobi(const double*a,double*v,double*w){double t[9];for(int i=0;i<9;++i)t[i]=a[i];bxo_jacobi3(t,v,w);}
+int t_kabsch(const double*H,double*R){return bxo_kabsch_from_H(H,R);}
+"""
+
+
+def _lib(tmp_path_factory):
+    d = tmp_path_factory.mktemp("detmath")
+    src = d / "shim.c"
+    src.write_text(SHIM)
+    so = d / "shim.so"
+    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-I", os.path.join(ROOT, "oracle"),
+                           str(src), "-o", str(so), "-lm"])
+    return C.CDLL(str(so))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_detmath(tmp_path_factory):
+    L = _lib(tmp_path_factory)
+    rng = np.random.default_rng(0)
+    x = -rng.random(5000) * 90
+    o = np.zeros_like(x)
+    L.t_exp(_p(x), len(x), _p(o))
+    assert np.allclose(o, np.exp(x), rtol=2e-15, atol=0)
+    x = rng.random(5000) * 14 - 7
+    s, c = np.zeros_like(x), np.zeros_like(x)
+    L.t_sincos(_p(x), len(x), _p(s), _p(c))
+    assert np.abs(s - np.sin(x)).max() < 3e-16 and np.abs(c - np.cos(x)).max() < 3e-16
+    x = np.concatenate([rng.random(5000) * 2 - 1, [1.0, -1.0, 0.0, 0.5, -0.5, 1 - 1e-12]])
+    o = np.zeros_like(x)
+    L.t_acos(_p(x), len(x), _p(o))
+    assert np.abs(o - np.arccos(x)).max() < 2e-15
+    x = np.concatenate([rng.random(5000), [1e-300, 1.0, 0.001, 1 - 1e-9]])
+    x = x[x > 0]
+    o = np.zeros_like(x)
+    L.t_log(_p(x), len(x), _p(o))
+    assert np.allclose(o, np.log(x), rtol=4e-15, atol=1e-16)
+    # fp32 results agree with correctly-rounded libm results to <= 1 ulp
+    xf = (rng.random(2000) * 6.3).astype(np.float32)
+    s, c = np.zeros(2000), np.zeros(2000)
+    L.t_sincos(_p(xf.astype(np.float64)), 2000, _p(s), _p(c))
+    assert np.abs(s.astype(np.float32) - np.sin(xf.astype(np.float64)).astype(np.float32)).max() <= 6e-8
+
+
+def test_jacobi_and_kabsch(tmp_path_factory):
+    L = _lib(tmp_path_factory)
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        B = rng.standard_normal((3, 3))
+        A = B @ B.T
+        v, w = np.zeros(9), np.zeros(3)
+        L.t_jacobi(_p(np.ascontiguousarray(A)), _p(v), _p(w))
+        V = v.reshape(3, 3)
+        assert np.allclose(V @ np.diag(w) @ V.T, A, atol=1e-12)
+        assert np.allclose(np.sort(w), np.linalg.eigvalsh(A), atol=1e-12)
+    for rank2 in (False, True):
+        for _ in range(100):
+            n = 3 if rank2 else 20
+            a = rng.standard_normal((n, 3))
+            Rg, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+            if np.linalg.det(Rg) < 0:
+                Rg[:, 0] *= -1
+            b = a @ Rg.T
+            a0, b0 = a - a.mean(0), b - b.mean(0)
+            H = np.ascontiguousarray(a0.T @ b0)
+            R = np.zeros(9)
+            assert L.t_kabsch(_p(H), _p(R)) == 1
+            assert np.allclose(R.reshape(3, 3), Rg, atol=1e-9)
+    # reflection case: the closest PROPER rotation is returned (det = +1)
+    a = rng.standard_normal((30, 3))
+    b = a * np.array([1, 1, -1.0])
+    R = np.zeros(9)
+    L.t_kabsch(_p(np.ascontiguousarray(a.T @ b)), _p(R))
+    assert abs(np.linalg.det(R.reshape(3, 3)) - 1) < 1e-9
+    U, S, Vt = np.linalg.svd(a.T @ b)
+    Rref = Vt.T @ np.diag([1, 1, np.linalg.det(Vt.T @ U.T)]) @ U.T
+    assert np.allclose(R.reshape(3, 3), Rref, atol=1e-9)
+    # rank < 2 is rejected
+    assert L.t_kabsch(_p(np.zeros(9)), _p(R)) == 0
