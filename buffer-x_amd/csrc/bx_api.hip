@@ -18,6 +18,24 @@ void bx_set_error(const char* fmt, ...)
 
 namespace {
 
+struct ProfEvt { hipEvent_t a, b; int tag; };
+struct ProfScope {
+    bx_ctx* c; hipStream_t s; ProfEvt e; bool on;
+    ProfScope(bx_ctx* c_, hipStream_t s_, int tag) : c(c_), s(s_), on(c_->prof_on != 0)
+    {
+        if (!on) return;
+        e.tag = tag;
+        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(e.a, s);
+    }
+    ~ProfScope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(e.b, s);
+        static_cast<std::vector<ProfEvt>*>(c->prof)->push_back(e);
+    }
+};
+
 struct Carver {
     char* base;
     size_t off;
@@ -256,6 +274,7 @@ int bx_create(int device_id, const bx_params* params, bx_ctx** out)
     memset(c, 0, sizeof(*c));
     c->device = device_id;
     c->p = p;
+    c->prof = new std::vector<ProfEvt>();
     size_t total = 0;
     carve(c, nullptr, &total);
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->arena), total);
@@ -299,6 +318,28 @@ int bx_destroy(bx_ctx* c)
 }
 
 int64_t bx_workspace_bytes(const bx_ctx* c) { return c ? c->arena_bytes : 0; }
+
+int bx_profile_enable(bx_ctx* c, int32_t on)
+{
+    if (!c) { bx_set_error("null context"); return BX_ERR_ARG; }
+    c->prof_on = on ? 1 : 0;
+    return BX_OK;
+}
+
+int bx_profile_read(bx_ctx* c, double* ms_out, int32_t* count_out)
+{
+    if (!c || !ms_out || !count_out) { bx_set_error("bx_profile_read: null"); return BX_ERR_ARG; }
+    for (int i = 0; i < BX_PROF_TAGS; ++i) { ms_out[i] = 0.0; count_out[i] = 0; }
+    auto* v = static_cast<std::vector<ProfEvt>*>(c->prof);
+    for (auto& e : *v) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess && e.tag >= 0 && e.tag < BX_PROF_TAGS) { ms_out[e.tag] += ms; count_out[e.tag] += 1; }
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    v->clear();
+    return BX_OK;
+}
 
 int bx_load_weights(bx_ctx* c, const bx_weights* w)
 {
@@ -493,7 +534,7 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
     const float* clouds[2] = {src, tgt};
     const int ns[2] = {n_src, n_tgt};
     const int32_t* perms[2] = {perm_src, perm_tgt};
-    if ((rc = bxk_fps(c, s, clouds, ns, 2, KM, c->fps_idx, c->kpts)) != BX_OK) return rc;
+    { ProfScope ps(c, s, 0); if ((rc = bxk_fps(c, s, clouds, ns, 2, KM, c->fps_idx, c->kpts)) != BX_OK) return rc; }
 
     // (2) radius estimation histogram: the LARGER cloud and its keypoints (models/BUFFERX.py:654-665), once per pair
     const int big = n_src > n_tgt ? 0 : 1;
@@ -504,25 +545,25 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
         rpts = c->sub_pts;
         rn = 200000;
     }
-    if ((rc = bxk_radius_hist(c, s, rpts, rn, c->kpts[big], NK)) != BX_OK) return rc;
+    { ProfScope ps(c, s, 1); if ((rc = bxk_radius_hist(c, s, rpts, rn, c->kpts[big], NK)) != BX_OK) return rc; }
 
     const bool early = p.enable_early_exit != 0;
     int ransac_calls = 0;
     for (int i = 0; i < S; ++i) {
         c->skip = (early && i > 0) ? &st->done : nullptr;
-        if ((rc = bxk_radius_bisect(c, s, (int64_t)ns[big], NK, p.search_radius_thresholds[i], &st->des_r[i])) != BX_OK) return rc;
+        { ProfScope ps(c, s, 1); if ((rc = bxk_radius_bisect(c, s, (int64_t)ns[big], NK, p.search_radius_thresholds[i], &st->des_r[i])) != BX_OK) return rc; }
         for (int cl = 0; cl < 2; ++cl) {
-            if ((rc = bx_permute_launch(s, clouds[cl], perms[cl] + (size_t)i * ns[cl], ns[cl], c->pts_perm, c->skip)) != BX_OK) return rc;
-            if ((rc = bxk_ball_group(c, s, c->pts_perm, ns[cl], c->kpts[cl], K, &st->des_r[i], P, nullptr, c->patches)) != BX_OK) return rc;
-            if ((rc = bxk_patch_features(c, s, c->patches, K, P, &st->des_r[i], aligned_z, c->Rpatch[cl], c->feat)) != BX_OK) return rc;
-            if ((rc = desc_stack(c, s, c->feat, K, c->desc_out[cl], c->equi[cl], nullptr)) != BX_OK) return rc;
+            { ProfScope ps(c, s, 11); if ((rc = bx_permute_launch(s, clouds[cl], perms[cl] + (size_t)i * ns[cl], ns[cl], c->pts_perm, c->skip)) != BX_OK) return rc; }
+            { ProfScope ps(c, s, 2); if ((rc = bxk_ball_group(c, s, c->pts_perm, ns[cl], c->kpts[cl], K, &st->des_r[i], P, nullptr, c->patches)) != BX_OK) return rc; }
+            { ProfScope ps(c, s, 3); if ((rc = bxk_patch_features(c, s, c->patches, K, P, &st->des_r[i], aligned_z, c->Rpatch[cl], c->feat)) != BX_OK) return rc; }
+            { ProfScope ps(c, s, 4); if ((rc = desc_stack(c, s, c->feat, K, c->desc_out[cl], c->equi[cl], nullptr)) != BX_OK) return rc; }
         }
-        if ((rc = bxk_mutual(c, s, c->desc_out[0], K, c->desc_out[1], K, c->s_mids, c->t_mids, &st->m_scale)) != BX_OK) return rc;
-        if ((rc = pose_stack(c, s, c->equi[0], c->equi[1], c->s_mids, c->t_mids, &st->m_scale, K, c->ind, nullptr)) != BX_OK) return rc;
+        { ProfScope ps(c, s, 6); if ((rc = bxk_mutual(c, s, c->desc_out[0], K, c->desc_out[1], K, c->s_mids, c->t_mids, &st->m_scale)) != BX_OK) return rc; }
+        { ProfScope ps(c, s, 7); if ((rc = pose_stack(c, s, c->equi[0], c->equi[1], c->s_mids, c->t_mids, &st->m_scale, K, c->ind, nullptr)) != BX_OK) return rc; }
         if ((rc = bxk_hypotheses(s, c->ind, c->s_mids, c->t_mids, &st->m_scale, K, c->Rpatch[0], c->Rpatch[1], c->kpts[0], c->kpts[1],
                                  c->R_cat, c->t_cat, c->ss_cat, c->tt_cat, &st->M, c->skip)) != BX_OK) return rc;
         hipLaunchKernelGGL(accumulate_kernel, dim3(1), dim3(64), 0, s, st, i, c->skip);
-        if ((rc = bxk_consensus(c, s, c->R_cat, c->t_cat, c->ss_cat, c->tt_cat, &st->M, (i + 1) * K, c->inlier_ind, &st->C, &st->best)) != BX_OK) return rc;
+        { ProfScope ps(c, s, 8); if ((rc = bxk_consensus(c, s, c->R_cat, c->t_cat, c->ss_cat, c->tt_cat, &st->M, (i + 1) * K, c->inlier_ind, &st->C, &st->best)) != BX_OK) return rc; }
         if (early && i == 0) {
             if ((rc = bxk_ransac(c, s, c->ss_cat, c->tt_cat, c->inlier_ind, &st->C, K, bx_mix64(seed, 0x5AC0000ULL + ransac_calls), nullptr, nullptr, nullptr)) != BX_OK) return rc;
             ++ransac_calls;
@@ -530,12 +571,13 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
         }
     }
     // final pose estimation unless the early exit was taken (models/BUFFERX.py:449-457)
+    { ProfScope ps(c, s, 9);
     if ((rc = bxk_ransac(c, s, c->ss_cat, c->tt_cat, c->inlier_ind, &st->C, S * K, bx_mix64(seed, 0x5AC0000ULL + ransac_calls), nullptr, nullptr,
-                         early ? &st->done : nullptr)) != BX_OK) return rc;
+                         early ? &st->done : nullptr)) != BX_OK) return rc; }
     c->skip = nullptr;
     if (p.pose_refine) {
         hipLaunchKernelGGL(pose_to_float_kernel, dim3(1), dim3(64), 0, s, st);
-        if ((rc = bxk_refine(c, s, c->ss_cat, c->tt_cat, &st->M, S * K, st->Tf, &st->refine_iters)) != BX_OK) return rc;
+        { ProfScope ps(c, s, 10); if ((rc = bxk_refine(c, s, c->ss_cat, c->tt_cat, &st->M, S * K, st->Tf, &st->refine_iters)) != BX_OK) return rc; }
     }
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, s, st, c->err_flag, p.pose_refine, S, c->result_dev);
     BX_LAUNCH_CHECK();

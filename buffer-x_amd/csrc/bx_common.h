@@ -102,6 +102,8 @@ struct bx_ctx {
     bx_result* result_dev;              // device staging of the result
     int32_t* err_flag;                  // device error flag
     const int32_t* skip;                // device flag: non-zero => pipeline kernels return immediately (early exit)
+    int prof_on;
+    void* prof;                         // std::vector<ProfEvt>* (bx_api.hip)
 };
 
 constexpr int BX_RANSAC_BATCH = 4096;

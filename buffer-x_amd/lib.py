@@ -40,6 +40,7 @@ class BxResult(C.Structure):
 
 
 EXPORTS = ["bx_create", "bx_destroy", "bx_last_error", "bx_load_weights", "bx_workspace_bytes", "bx_register_pair",
+           "bx_profile_enable", "bx_profile_read",
            "bx_fps", "bx_radius", "bx_permute", "bx_ball_group", "bx_patch_features", "bx_desc_net", "bx_conv_layer",
            "bx_mutual", "bx_pose_net", "bx_hypotheses", "bx_consensus", "bx_ransac", "bx_refine"]
 
@@ -169,6 +170,19 @@ class Context:
         for i, L in enumerate(pw["pose"]):
             w.pose_w[i], w.pose_b[i] = ptr(L["W"]), ptr(L["b"])
         _chk(self.lib.bx_load_weights(self.handle, C.byref(w)), "bx_load_weights")
+
+    PROF_TAGS = ["fps", "radius", "neighbour_gather", "patch_features", "desc_conv", "desc_head", "mutual", "pose_net",
+                 "consensus", "ransac", "refine", "permute"]
+
+    def profile_enable(self, on=True):
+        _chk(self.lib.bx_profile_enable(self.handle, C.c_int32(int(on))), "bx_profile_enable")
+
+    def profile_read(self):
+        """{stage: (total_ms, launches)} since the last read; call after synchronising the stream."""
+        ms = (C.c_double * 16)()
+        cnt = (C.c_int32 * 16)()
+        _chk(self.lib.bx_profile_read(self.handle, ms, cnt), "bx_profile_read")
+        return {t: (ms[i], cnt[i]) for i, t in enumerate(self.PROF_TAGS)}
 
     # ---------------------------------------------------------------- helpers
     def _stream(self):
@@ -322,13 +336,20 @@ class Context:
                                 self._p(T), self._p(it)), "bx_refine")
         return T, it
 
+    def new_result(self):
+        """BxResult living in pinned host memory (so the final D2H copy is truly asynchronous)."""
+        buf = self.torch.zeros(C.sizeof(BxResult), dtype=self.torch.uint8).pin_memory()
+        res = BxResult.from_address(buf.data_ptr())
+        res._pinned = buf
+        return res
+
     # ---------------------------------------------------------------- whole pair (async)
     def register_pair_async(self, src, tgt, aligned_z, perm_src, perm_tgt, seed, result=None):
         """Enqueue one pair on the current stream.  Returns the BxResult (valid after stream sync)."""
         t = self.torch
         src, tgt = self._dev(src, t.float32), self._dev(tgt, t.float32)
         perm_src, perm_tgt = self._dev(perm_src, t.int32), self._dev(perm_tgt, t.int32)
-        res = result if result is not None else BxResult()
+        res = result if result is not None else self.new_result()
         _chk(self.lib.bx_register_pair(self.handle, self._stream(), self._p(src), C.c_int32(src.shape[0]), self._p(tgt),
                                        C.c_int32(tgt.shape[0]), C.c_int32(int(aligned_z)), self._p(perm_src), self._p(perm_tgt),
                                        C.c_uint64(seed & (2**64 - 1)), C.byref(res)), "bx_register_pair")

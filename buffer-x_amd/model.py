@@ -1,0 +1,150 @@
+"""Drop-in `BufferX` for the reference's benchmark harness (test.py:83-106,145).
+
+Mirrors reference models/BUFFERX.py:72-84,130-467 at the Python surface:
+  * `BufferX(cfg)` is an nn.Module whose state_dict() has exactly the reference's 105 tensors
+    (Desc.pnt_layer.*, Desc.pool_layer.*, Desc.conv_net.ops.*, Pose.conv.ops.*), so test.py:86-94's
+    substring-filtered load_state_dict works, and it survives .to(device) / nn.DataParallel / .eval().
+  * `forward(data_source)` takes the dataloader dict (keys src_fds_pcd, tgt_fds_pcd, is_aligned_to_global_z;
+    dataset/dataloader.py:108-122) and returns
+        (pose 4x4 ndarray, [desc_t, pose_t, optim_t], num_inliers, num_mutual_inliers, num_inlier_ind, scales_used).
+The nn layers exist only to own the parameters (PyTorch = weight loading); the arithmetic runs in the HIP
+library through the C-ABI (lib.Context.register_pair).  Inference only: config.stage must be "test".
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import lib, weights
+
+
+class _Ops(nn.Module):
+    """Container exposing `.ops` like the reference's Cyclindrical_ConvNet / CostBlock (models/patchnet.py:16-47,151-189)."""
+
+    def __init__(self, layers):
+        super().__init__()
+        self.ops = nn.ModuleList(layers)
+
+
+def _cyl_net():
+    # models/patchnet.py:72-84
+    ops = [nn.Conv3d(16, 64, (3, 3, 3)), nn.BatchNorm3d(64, affine=False), nn.ReLU(inplace=True)]
+    for ci, co in [(64, 64), (64, 128), (128, 128), (128, 64), (64, 64), (64, 32)]:
+        ops += [nn.Conv2d(ci, co, (3, 3)), nn.BatchNorm2d(co, affine=False), nn.ReLU(inplace=True)]
+    ops += [nn.Conv2d(32, 32, (3, 3))]
+    return _Ops(ops)
+
+
+def _cost_net():
+    # models/patchnet.py:196-210
+    spec = [(32, 32, (3, 3, 3)), (32, 64, (3, 3, 3)), (64, 64, (3, 1, 3)), (64, 128, (3, 1, 3)), (128, 128, (3, 1, 3)),
+            (128, 64, (3, 1, 3)), (64, 64, (3, 1, 3)), (64, 32, (3, 1, 3)), (32, 32, (3, 1, 3))]
+    ops = []
+    for ci, co, k in spec:
+        ops += [nn.Conv3d(ci, co, k), nn.BatchNorm3d(co, affine=False), nn.ReLU(inplace=True)]
+    ops += [nn.Conv3d(32, 20, (2, 1, 2))]
+    return _Ops(ops)
+
+
+class _Desc(nn.Module):
+    """Parameter holder with the key layout of MiniSpinNet (models/patch_embedder.py:26-41)."""
+
+    def __init__(self):
+        super().__init__()
+        self.pnt_layer = nn.Sequential(nn.Conv2d(3, 16, (1, 1)), nn.BatchNorm2d(16), nn.ReLU(True))
+        self.pool_layer = nn.Sequential(nn.Conv2d(32, 16, (1, 1)), nn.BatchNorm2d(16), nn.ReLU(True),
+                                        nn.Conv2d(16, 1, (1, 1)), nn.BatchNorm2d(1), nn.ReLU(True))
+        self.conv_net = _cyl_net()
+
+
+class _Pose(nn.Module):
+    """Parameter holder with the key layout of CostVolume (models/BUFFERX.py:39-49)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv = _cost_net()
+
+
+class BufferX(nn.Module):
+    def __init__(self, config, max_points=None):
+        super().__init__()
+        self.config = config
+        if config.stage != "test":
+            raise NotImplementedError("bufferx_amd.BufferX implements the inference path only (config.stage == 'test')")
+        if config.match.get("pose_estimator", "ransac") != "ransac":
+            # the reference falls back to RANSAC when kiss_matcher is not importable (models/pose_estimator.py:74-82)
+            print("Warning: only the RANSAC pose estimator is implemented; falling back to RANSAC.")
+        self.Desc = _Desc()
+        self.Pose = _Pose()
+        self._ctx = None
+        self._ctx_key = None
+        self._max_points = max_points
+
+    # ------------------------------------------------------------------ HIP context management
+    def _context(self, device_index, n_max):
+        cfg = self.config
+        key = (device_index, cfg.patch.num_fps, cfg.patch.num_points_per_patch, cfg.patch.num_scales,
+               tuple(cfg.patch.search_radius_thresholds), cfg.match.dist_th, cfg.match.inlier_th, cfg.match.similar_th,
+               cfg.match.confidence, cfg.match.iter_n, bool(cfg.match.get("enable_early_exit", True)),
+               cfg.match.get("early_exit_min_inliers", 15), cfg.test.pose_refine is True)
+        cap = self._max_points or 0
+        if self._ctx is not None and self._ctx_key == key and n_max <= self._ctx_cap:
+            return self._ctx
+        if self._ctx is not None:
+            self._ctx.close()
+        cap = max(cap, int(n_max * 1.25) + 1024)
+        packed = weights.fold_and_pack(self.state_dict())
+        self._ctx = lib.Context(cfg, max_points=cap, device=device_index, packed_weights=packed)
+        self._ctx_key, self._ctx_cap = key, cap
+        return self._ctx
+
+    def refresh_weights(self):
+        """Call after load_state_dict if a forward already ran (weights are folded/uploaded on first use)."""
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.refresh_weights()
+        return r
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, data_source):
+        cfg = self.config
+        src, tgt = data_source["src_fds_pcd"], data_source["tgt_fds_pcd"]
+        if not (isinstance(src, torch.Tensor) and src.is_cuda):
+            raise RuntimeError("bufferx_amd.BufferX.forward needs CUDA/HIP tensors (there is no CPU fallback)")
+        src = src.reshape(-1, 3).float().contiguous()
+        tgt = tgt.reshape(-1, 3).float().contiguous()
+        aligned = data_source["is_aligned_to_global_z"]
+        if isinstance(aligned, torch.Tensor):
+            aligned = bool(aligned.reshape(-1)[0].item())
+        S = cfg.patch.num_scales
+        assert S == len(cfg.patch.search_radius_thresholds), \
+            f"num_scales {S} != num_thresholds {len(cfg.patch.search_radius_thresholds)}"  # models/BUFFERX.py:276-278
+        dev = src.device.index if src.device.index is not None else torch.cuda.current_device()
+        ctx = self._context(dev, max(src.shape[0], tgt.shape[0]))
+        # the reference draws one permutation per Desc call from numpy's global RNG (models/patch_embedder.py:96),
+        # in the order scale0-src, scale0-tgt, scale1-src, ... ; the same calls are made here so that a seeded
+        # np.random reproduces it.  Open3D's RANSAC is unseeded in the reference; the seed is drawn from np.random.
+        ps, pt = [], []
+        for _ in range(S):
+            ps.append(np.random.choice(src.shape[0], src.shape[0], replace=False).astype(np.int32))
+            pt.append(np.random.choice(tgt.shape[0], tgt.shape[0], replace=False).astype(np.int32))
+        seed = int(np.random.randint(0, 2**31 - 1))
+        timing = bool(cfg.test.get("enable_timing", False))
+        ctx.profile_enable(timing)
+        res = ctx.register_pair(src, tgt, aligned, np.stack(ps), np.stack(pt), seed)
+        times = [0.0, 0.0, 0.0]
+        if timing:   # seconds, same three buckets as models/BUFFERX.py:310-316,466
+            pr = ctx.profile_read()
+            ms = lambda *tags: sum(pr[t][0] for t in tags)
+            times = [ms("fps", "radius", "permute", "neighbour_gather", "patch_features", "desc_conv", "desc_head", "mutual") / 1e3,
+                     ms("pose_net", "consensus") / 1e3, ms("ransac", "refine") / 1e3]
+        pose = np.array(res.pose, np.float64).reshape(4, 4)
+        if cfg.test.pose_refine is True:
+            pose = pose.astype(np.float32)   # the reference returns the fp32 refined pose (models/BUFFERX.py:461-463)
+        return pose, times, int(res.num_inliers), int(res.num_mutual), int(res.num_inlier_ind), int(res.scales_used)
+
+    def get_parameter(self):
+        return list(self.parameters())

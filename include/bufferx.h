@@ -106,6 +106,16 @@ int bx_load_weights(bx_ctx *ctx, const bx_weights *w);
 /* bytes of the per-context workspace arena (for DESIGN.md / capacity planning) */
 int64_t bx_workspace_bytes(const bx_ctx *ctx);
 
+/* ---- measurement hooks (hipEvent timers; reference utils/gpu_timer.py:3-33 semantics) -------------------
+ * When enabled, bx_register_pair brackets each stage with hipEvents on the caller's stream.  After the stream
+ * is synchronised bx_profile_read() adds up elapsed milliseconds / launch counts per stage tag and clears the
+ * event list.  Tags: 0 fps, 1 radius, 2 neighbour-gather (ball_group), 3 patch features, 4 Desc conv stack,
+ * 5 desc head, 6 mutual matching, 7 CostNet + soft-argmax, 8 hypotheses + consensus, 9 RANSAC, 10 refinement,
+ * 11 permute.  ms_out / count_out: HOST arrays of BX_PROF_TAGS entries.                                   */
+#define BX_PROF_TAGS 16
+int bx_profile_enable(bx_ctx *ctx, int32_t on);
+int bx_profile_read(bx_ctx *ctx, double *ms_out, int32_t *count_out);
+
 /* ---- whole pair: replaces BufferX.forward's inference branch, models/BUFFERX.py:257-467 -------
  * src/tgt: device float32 [n][3].  perm_src/perm_tgt: device int32 permutations, one per scale
  * ([num_scales][n], stands in for np.random.choice at models/patch_embedder.py:96).  seed drives the
