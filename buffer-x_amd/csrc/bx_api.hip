@@ -91,6 +91,15 @@ void carve(bx_ctx* c, char* base, size_t* total)
     c->refine_ws = cv.take<float>(SK * 2);
     c->refine_sel = cv.take<int32_t>(SK);
     c->sub_pts = cv.take<float>(NMAX > 200000 ? (size_t)200000 * 3 : 16);
+    c->ball_bbox = cv.take<int32_t>(8);
+    c->ball_grid = cv.take<BallGrid>(1);
+    c->ball_cnt = cv.take<int32_t>((size_t)BX_BALL_NCELL + 2 * 2048);
+    c->ball_start = cv.take<int32_t>((size_t)BX_BALL_NCELL + 2 * 2048);
+    c->ball_bsum = cv.take<int32_t>(BX_BALL_NCELL / 2048 + 2);
+    c->ball_cellrank = cv.take<int2>(NMAX);
+    c->ball_pts4 = cv.take<float4>(NMAX);
+    c->ball_sorted = cv.take<float4>(NMAX);
+    c->ball_dbg = cv.take<long long>(64 * 8);
     c->state = cv.take<PairState>(1);
     c->result_dev = cv.take<bx_result>(1);
     c->err_flag = cv.take<int32_t>(4);
@@ -318,6 +327,13 @@ int bx_destroy(bx_ctx* c)
 }
 
 int64_t bx_workspace_bytes(const bx_ctx* c) { return c ? c->arena_bytes : 0; }
+
+int bx_debug_read(bx_ctx* c, int64_t* out, int32_t n)
+{
+    if (!c || !out || n < 0 || n > 64 * 8) { bx_set_error("bx_debug_read: bad argument"); return BX_ERR_ARG; }
+    BX_HIP(hipMemcpy(out, c->ball_dbg, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost));
+    return BX_OK;
+}
 
 int bx_profile_enable(bx_ctx* c, int32_t on)
 {

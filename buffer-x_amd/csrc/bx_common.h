@@ -57,6 +57,15 @@ struct PairState {
     int32_t r_pad;
 };
 
+// uniform grid of the neighbour gather (k_ball.hip), rebuilt per launch on the device
+constexpr int BX_BALL_NCELL = 1 << 17;
+struct BallGrid {
+    float ox, oy, oz, inv_h, rpad;
+    int32_t dx, dy, dz, ncells;
+};
+// tuning knob (env BX_BALL_DIV, read once): cell edge = padded radius / div  (1..3)
+int bx_ball_div();
+
 struct bx_ctx {
     int device;
     bx_params p;
@@ -98,6 +107,15 @@ struct bx_ctx {
     float* refine_ws;                   // [8][S*K]
     int32_t* refine_sel;                // [S*K]
     float* sub_pts;                     // [200000][3] subsample buffer for radius estimation
+    // neighbour-gather grid (k_ball.hip)
+    int32_t* ball_bbox;                 // [8] ordered-int min/max
+    BallGrid* ball_grid;
+    int32_t *ball_cnt, *ball_start;     // [BX_BALL_NCELL + 2 tiles]
+    int32_t* ball_bsum;                 // per scan tile
+    int2* ball_cellrank;                // [max_points]
+    float4 *ball_pts4, *ball_sorted;    // [max_points] {x,y,z,0} in permuted order / {x,y,z,bits(i)} sorted by cell
+    int ball_attr_set;
+    long long* ball_dbg;                // [64][8] cycle stamps (BX_BALL_DEBUG)
     PairState* state;                   // device
     bx_result* result_dev;              // device staging of the result
     int32_t* err_flag;                  // device error flag
@@ -175,6 +193,19 @@ __device__ __forceinline__ int bx_wave_sum_i(int v)
     for (int s = 32; s >= 1; s >>= 1) v = v + __shfl_xor(v, s, 64);
     return v;
 }
+// inclusive prefix sum over the 64 lanes on the DPP network (no LDS round trips): Hillis-Steele inside each row of
+// 16 lanes (row_shr 1,2,4,8), then row_bcast15 / row_bcast31 carry the row totals (gfx9 DPP broadcasts)
+__device__ __forceinline__ int bx_wave_incl_scan_dpp(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
 // exclusive prefix sum over the wave
 __device__ __forceinline__ int bx_wave_excl_scan(int v, int lane)
 {

@@ -5,19 +5,28 @@
 // order of the (permuted) cloud, with fp32 d2 < r2 (strict, un-fused ((dx*dx+dy*dy)+dz*dz)); unfilled slots
 // repeat the first hit; slots equal to the first hit (except slot 0) and slot P-1 become the keypoint.
 //
-// Round-1 kernel (exact brute force, streaming):
-//   * one wave per keypoint, WPB keypoints per workgroup; the cloud streams through LDS in 2048-point SoA
-//     tiles shared by the workgroup's waves (coalesced HBM/L2 -> LDS once per workgroup);
-//   * each wave tests 64 points per step; the 64-bit ballot of the step is the hit BITMAP word for those 64
-//     points -- kept in a VGPR (lane w&63 owns word w) and flushed to LDS once per 64 steps, so the scan
-//     issues no per-step stores; the scan stops once P hits were seen (first-P semantics);
-//   * expansion: popcount prefix over the bitmap words, then output slot j finds its word by binary search
-//     and its bit by a 6-step select -- the P outputs are produced in order, idx and xyz written with
-//     coalesced stores.  Algorithmic HBM bytes: 12N + 12K + 4KP + 12KP.
+// Round-2 design (exact, grid-accelerated; replaces the O(K*N) streaming scan):
+//   1. a uniform grid with cell edge h >= r(1+pad) is built over the permuted cloud per launch (the radius only
+//      exists on the device): bbox -> counting sort by cell (atomic rank, 2-kernel scan, scatter).  A sorted
+//      entry is {x, y, z, bits(i)} with i = position in the permuted cloud, one 16-byte load per candidate.
+//   2. query: ONE wave per keypoint (64-thread workgroups, no barriers across waves).  The wave walks the <= 3x3
+//      (y,z) cell rows around the keypoint; a row's <= 3 x-cells are ONE contiguous range of the sorted array, so
+//      candidates stream in with coalesced 16-B loads.  Every hit sets bit i of an n-bit bitmap in LDS
+//      (ds_or_b32).  The bitmap restores the reference's order for free: set bits in increasing i ARE the
+//      ball_query output order, whatever order the candidates were visited in.
+//   3. ordered expansion: lane w owns bitmap word w of a 64-word group; popcount + wave prefix gives each lane the
+//      output rank of its first hit; it peels its bits (ctz) into an LDS index list, stopping at P.
+//   4. output: lane j reads list[j], gathers {x,y,z} with one 16-B load from the float4 copy of the cloud
+//      (L2 resident), applies the mask arithmetic and stores 12 contiguous bytes (global_store_dwordx3) -- a wave
+//      writes 768 contiguous bytes per instruction.
+//   Cell membership is monotone in the coordinate (fp32 subtract, multiply by a positive, floor, clamp), so a
+//   point with fp32 d2 < r2 always lies inside the visited cell range (pad covers the rounding of d2 and of q-r).
+// Algorithmic HBM bytes per launch: 12N + 12K + 4KP + 12KP; the tests done drop from K*N to
+// roughly K * (points in 27 cells).
 #include "bx_common.h"
+#include <cstdlib>
 
 namespace {
-constexpr int TILE = 2048;
 
 __global__ void permute_kernel(const float* __restrict__ pts, const int32_t* __restrict__ perm, int n, float* __restrict__ out,
                                const int32_t* __restrict__ skip)
@@ -32,136 +41,442 @@ __global__ void permute_kernel(const float* __restrict__ pts, const int32_t* __r
     }
 }
 
-__device__ __forceinline__ int select_bit(unsigned long long x, int r)
+// order-preserving float <-> int map for atomicMin / atomicMax
+__device__ __forceinline__ int f2ord(float f)
 {
-    int pos = 0;
-    int c = __popc((unsigned)(x & 0xffffffffu));
-    if (r >= c) { r -= c; pos += 32; x >>= 32; }
-    c = __popc((unsigned)(x & 0xffffu));
-    if (r >= c) { r -= c; pos += 16; x >>= 16; }
-    c = __popc((unsigned)(x & 0xffu));
-    if (r >= c) { r -= c; pos += 8; x >>= 8; }
-    c = __popc((unsigned)(x & 0xfu));
-    if (r >= c) { r -= c; pos += 4; x >>= 4; }
-    c = __popc((unsigned)(x & 0x3u));
-    if (r >= c) { r -= c; pos += 2; x >>= 2; }
-    c = (int)(x & 1u);
-    if (r >= c) { pos += 1; }
-    return pos;
+    int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+__global__ void bbox_init_kernel(int32_t* bbox, const int32_t* __restrict__ skip)
+{
+    if (skip && *skip) return;
+    if (threadIdx.x < 3) bbox[threadIdx.x] = 0x7fffffff;
+    else if (threadIdx.x < 6) bbox[threadIdx.x] = (int)0x80000000;
 }
 
-template <int WPB>
-__global__ __launch_bounds__(WPB * 64) void ball_group_kernel(const float* __restrict__ pts, int n,
-                                                              const float* __restrict__ kpts, int K,
-                                                              const double* __restrict__ radius, int P,
-                                                              int32_t* __restrict__ idx_out, float* __restrict__ patches,
-                                                              const int32_t* __restrict__ skip)
+// <= 64 workgroups; one device-scope atomic per workgroup and bound (same-address device atomics cost ~12 ns each)
+__global__ __launch_bounds__(1024) void bbox_kernel(const float* __restrict__ pts, int n, int32_t* bbox, const int32_t* __restrict__ skip)
+{
+    if (skip && *skip) return;
+    __shared__ float red[16][6];
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = pts[(size_t)i * 3 + c];
+            lo[c] = fminf(lo[c], v);
+            hi[c] = fmaxf(hi[c], v);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+            lo[c] = fminf(lo[c], __shfl_xor(lo[c], s, 64));
+            hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], s, 64));
+        }
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { red[wave][c] = lo[c]; red[wave][3 + c] = hi[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int c = threadIdx.x;
+        float v = red[0][c];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) v = c < 3 ? fminf(v, red[w][c]) : fmaxf(v, red[w][c]);
+        if (c < 3) atomicMin(&bbox[c], f2ord(v)); else atomicMax(&bbox[c], f2ord(v));
+    }
+}
+
+// one thread: grid geometry from the bbox and the device-side radius
+__global__ void grid_setup_kernel(const int32_t* __restrict__ bbox, const double* __restrict__ radius, int div, BallGrid* g,
+                                  const int32_t* __restrict__ skip)
+{
+    if (skip && *skip) return;
+    if (threadIdx.x != 0) return;
+    float lo[3], hi[3], ext[3];
+    float maxabs = 1.0f;
+    for (int c = 0; c < 3; ++c) {
+        lo[c] = ord2f(bbox[c]);
+        hi[c] = ord2f(bbox[3 + c]);
+        if (!(hi[c] >= lo[c])) { lo[c] = 0.f; hi[c] = 0.f; }   // empty / NaN cloud
+        ext[c] = hi[c] - lo[c];
+        maxabs = fmaxf(maxabs, fmaxf(fabsf(lo[c]), fabsf(hi[c])));
+    }
+    float r = (float)(*radius);
+    if (!(r > 0.f)) r = 0.f;
+    // pad: covers the rounding of d2 (a hit can have |dx| up to r(1+5 eps)) and of fl(q -+ rpad)
+    float rpad = r + (r * 1.0e-3f + 4.0e-7f * maxabs);
+    float emax = fmaxf(ext[0], fmaxf(ext[1], ext[2]));
+    float h = fmaxf(rpad / (float)div, fmaxf(emax * (1.0f / 1024.0f), 1.0e-20f));
+    int d[3];
+    for (int it = 0; it < 200; ++it) {
+        float inv = 1.0f / h;
+        long long tot = 1;
+        for (int c = 0; c < 3; ++c) {
+            float f = floorf(ext[c] * inv);
+            d[c] = (int)fminf(f, 1023.0f) + 1;
+            tot *= d[c];
+        }
+        if (tot <= BX_BALL_NCELL) break;
+        h = h * 1.2599211f;
+    }
+    g->ox = lo[0]; g->oy = lo[1]; g->oz = lo[2];
+    g->inv_h = 1.0f / h;
+    g->rpad = rpad;
+    g->dx = d[0]; g->dy = d[1]; g->dz = d[2];
+    g->ncells = d[0] * d[1] * d[2];
+}
+
+__device__ __forceinline__ int cell_coord(float x, float o, float inv_h, int d)
+{
+    float f = floorf((x - o) * inv_h);
+    f = fminf(fmaxf(f, 0.0f), (float)(d - 1));   // NaN -> 0
+    return (int)f;
+}
+
+// Rank of every point inside its cell (the order inside a cell is arbitrary; the query result does not depend on
+// it).  Same-address device atomics serialise (~2 ns each measured with 100 hot cells), so when the grid fits the
+// 64 KiB LDS histogram each workgroup ranks its points with LDS atomics and reserves one range per (workgroup,
+// cell) with a single device atomic; finer grids (little contention) use the device atomic per point.
+constexpr int COUNT_LDS_CELLS = 16384;
+constexpr int COUNT_PPT = 4;   // points per thread (register-resident between the two phases)
+
+__global__ __launch_bounds__(1024) void cell_count_kernel(const float* __restrict__ pts, int n, const BallGrid* __restrict__ g,
+                                                          int32_t* __restrict__ cnt, int2* __restrict__ cellrank,
+                                                          float4* __restrict__ pts4, const int32_t* __restrict__ skip)
+{
+    if (skip && *skip) return;
+    __shared__ int hist[COUNT_LDS_CELLS];
+    const float ox = g->ox, oy = g->oy, oz = g->oz, ih = g->inv_h;
+    const int dx = g->dx, dy = g->dy, dz = g->dz, ncells = g->ncells;
+    const bool use_lds = ncells <= COUNT_LDS_CELLS;
+    const int tid = threadIdx.x;
+    if (use_lds) {
+        for (int c = tid; c < ncells; c += 1024) hist[c] = 0;
+        __syncthreads();
+    }
+    int cell[COUNT_PPT], rank[COUNT_PPT];
+    const int base = blockIdx.x * (1024 * COUNT_PPT);
+#pragma unroll
+    for (int u = 0; u < COUNT_PPT; ++u) {
+        const int i = base + u * 1024 + tid;
+        cell[u] = -1; rank[u] = 0;
+        if (i < n) {
+            float x = pts[(size_t)i * 3], y = pts[(size_t)i * 3 + 1], z = pts[(size_t)i * 3 + 2];
+            pts4[i] = make_float4(x, y, z, 0.f);
+            cell[u] = (cell_coord(z, oz, ih, dz) * dy + cell_coord(y, oy, ih, dy)) * dx + cell_coord(x, ox, ih, dx);
+            rank[u] = use_lds ? atomicAdd(&hist[cell[u]], 1) : atomicAdd(&cnt[cell[u]], 1);
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int c = tid; c < ncells; c += 1024) {
+            const int h = hist[c];
+            if (h > 0) hist[c] = atomicAdd(&cnt[c], h);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < COUNT_PPT; ++u) {
+        const int i = base + u * 1024 + tid;
+        if (i < n) cellrank[i] = make_int2(cell[u], rank[u] + (use_lds ? hist[cell[u]] : 0));
+    }
+}
+
+constexpr int SCAN_TILE = 2048;   // cells per 256-thread workgroup
+
+__global__ __launch_bounds__(256) void scan_sums_kernel(const int32_t* __restrict__ cnt, const BallGrid* __restrict__ g,
+                                                        int32_t* __restrict__ bsum, const int32_t* __restrict__ skip)
+{
+    if (skip && *skip) return;
+    __shared__ int ws[4];
+    const int base = blockIdx.x * SCAN_TILE;
+    int s = 0;
+    if (base <= g->ncells) {
+        const int4* p = reinterpret_cast<const int4*>(cnt + base) + threadIdx.x * 2;
+        int4 a = p[0], b = p[1];
+        s = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
+    }
+    s = bx_wave_sum_i(s);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+// exclusive scan of cnt[0..ncells] -> start[0..ncells] (cnt[ncells] == 0, so start[ncells] == n)
+__global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restrict__ cnt, const BallGrid* __restrict__ g,
+                                                         const int32_t* __restrict__ bsum, int32_t* __restrict__ start,
+                                                         const int32_t* __restrict__ skip)
+{
+    if (skip && *skip) return;
+    __shared__ int ws[4];
+    __shared__ int boff;
+    const int base = blockIdx.x * SCAN_TILE;
+    if (base > g->ncells) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (wave == 0) {   // offset of this tile = sum of the preceding tiles (<= BX_BALL_NCELL / SCAN_TILE + 1 values)
+        int v = 0;
+        for (int b = lane; b < (int)blockIdx.x; b += 64) v += bsum[b];
+        v = bx_wave_sum_i(v);
+        if (lane == 0) boff = v;
+    }
+    const int4* p = reinterpret_cast<const int4*>(cnt + base) + tid * 2;
+    int4 a = p[0], b = p[1];
+    int tsum = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
+    int inc = bx_wave_incl_scan_dpp(tsum);
+    if (lane == 63) ws[wave] = inc;
+    __syncthreads();
+    int off = boff + (inc - tsum);
+    for (int w = 0; w < wave; ++w) off += ws[w];
+    int4 oa, ob;
+    oa.x = off; oa.y = oa.x + a.x; oa.z = oa.y + a.y; oa.w = oa.z + a.z;
+    ob.x = oa.w + a.w; ob.y = ob.x + b.x; ob.z = ob.y + b.y; ob.w = ob.z + b.z;
+    int4* o = reinterpret_cast<int4*>(start + base) + tid * 2;
+    o[0] = oa; o[1] = ob;
+}
+
+__global__ __launch_bounds__(256) void cell_scatter_kernel(const float4* __restrict__ pts4, int n, const int2* __restrict__ cellrank,
+                                                           const int32_t* __restrict__ start, float4* __restrict__ sorted,
+                                                           const int32_t* __restrict__ skip)
+{
+    if (skip && *skip) return;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int2 cr = cellrank[i];
+    float4 p = pts4[i];
+    p.w = __int_as_float(i);
+    sorted[start[cr.x] + cr.y] = p;
+}
+
+struct F3 { float x, y, z; };   // 4-byte aligned triple: stores compile to global_store_dwordx3
+
+constexpr int QU = 8;            // candidate loads in flight per lane
+constexpr int MAXROWS = 63;      // (y,z) cell rows kept in the per-wave row table (one lane each)
+
+// Bit i of the hit bitmap: lane (i>>6)>>LOGC owns the 64<<LOGC consecutive indices starting at lane*(64<<LOGC);
+// its slot-th 64-bit word sits at bm64[slot*64 + lane] (conflict-free for the owner's ds_read_b64 sweep).
+template <int LOGC>
+__device__ __forceinline__ void set_hit(unsigned int* bm32, int i)
+{
+    const int w = i >> 6;
+    const int a64 = ((w & ((1 << LOGC) - 1)) << 6) + (w >> LOGC);
+    atomicOr(&bm32[a64 * 2 + ((i >> 5) & 1)], 1u << (i & 31));
+}
+
+// One wave per keypoint.  LOGC: log2 of the 64-bit bitmap words per lane (n <= 4096 << LOGC).
+// LDS: max(bitmap, index list) -- the list overwrites the bitmap once every lane holds its words in registers.
+// wave-local ordering of LDS traffic: a wave's DS instructions execute in program order, so cross-lane hand-offs
+// inside ONE wave only need the compiler not to reorder them (no s_barrier: the four waves of a workgroup are
+// independent keypoints and never wait for each other)
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int QW = 4;            // waves (= keypoints) per workgroup
+
+template <int LOGC>
+__global__ __launch_bounds__(64 * QW) void ball_query_kernel(const float4* __restrict__ sorted, const int32_t* __restrict__ start,
+                                                        const BallGrid* __restrict__ g, const float4* __restrict__ pts4,
+                                                        const float* __restrict__ kpts, int K,
+                                                        const double* __restrict__ radius, int P, int32_t* __restrict__ idx_out,
+                                                        float* __restrict__ patches, const int32_t* __restrict__ skip,
+                                                        long long* __restrict__ dbg)
 {
     if (skip && *skip) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int W64 = (n + 63) >> 6;
-    float* sx = reinterpret_cast<float*>(smem);
-    float* sy = sx + TILE;
-    float* sz = sy + TILE;
-    unsigned long long* bm_all = reinterpret_cast<unsigned long long*>(sz + TILE);
-    int* pf_all = reinterpret_cast<int*>(bm_all + (size_t)WPB * W64);
+    long long t0 = 0;
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * QW + (threadIdx.x >> 6);
+    if (q >= K) return;
+    const bool tr = dbg != nullptr && (q % 79) == 0 && q / 79 < 60;
+    long long* td = dbg + (q / 79) * 8;
+    if (tr) { t0 = __builtin_readcyclecounter(); td[0] = t0; }
+#define BX_TR(k) do { if (tr) td[k] = __builtin_readcyclecounter() - t0; } while (0)
+    constexpr int C = 1 << LOGC;
+    const size_t wbytes = ((size_t)C * 512 > (size_t)P * 4) ? (size_t)C * 512 : (size_t)P * 4;
+    char* wmem = smem + (threadIdx.x >> 6) * wbytes;   // this wave's private slice
+    unsigned long long* bm64 = reinterpret_cast<unsigned long long*>(wmem);
+    unsigned int* bm32 = reinterpret_cast<unsigned int*>(wmem);
+    int* list = reinterpret_cast<int*>(wmem);           // [P], aliases the bitmap (see the hand-off below)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q = blockIdx.x * WPB + wave;
-    unsigned long long* bm = bm_all + (size_t)wave * W64;
-    int* pf = pf_all + (size_t)wave * W64;
+#pragma unroll
+    for (int s = 0; s < C; ++s) bm64[s * 64 + lane] = 0ULL;
 
     const float r = (float)(*radius);
     const float r2 = r * r;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    bool done = q >= K;
-    if (!done) { qx = kpts[(size_t)q * 3]; qy = kpts[(size_t)q * 3 + 1]; qz = kpts[(size_t)q * 3 + 2]; }
+    const float qx = kpts[(size_t)q * 3], qy = kpts[(size_t)q * 3 + 1], qz = kpts[(size_t)q * 3 + 2];
+    const float ox = g->ox, oy = g->oy, oz = g->oz, ih = g->inv_h, rp = g->rpad;
+    const int dx = g->dx, dy = g->dy, dz = g->dz;
+    const int xlo = cell_coord(qx - rp, ox, ih, dx), xhi = cell_coord(qx + rp, ox, ih, dx);
+    const int ylo = cell_coord(qy - rp, oy, ih, dy), yhi = cell_coord(qy + rp, oy, ih, dy);
+    const int zlo = cell_coord(qz - rp, oz, ih, dz), zhi = cell_coord(qz + rp, oz, ih, dz);
+    const int ny = yhi - ylo + 1, nz = zhi - zlo + 1;
+    const int R = ny * nz;
+    BX_TR(1);
 
-    int total = 0;      // hits seen so far (wave-uniform)
-    int wused = 0;      // bitmap words written
-    unsigned long long myword = 0;
-
-    for (int tile0 = 0; tile0 < n; tile0 += TILE) {
-        for (int i = tid; i < TILE; i += WPB * 64) {
-            int j = tile0 + i;
-            if (j < n) {
-                sx[i] = pts[(size_t)j * 3 + 0];
-                sy[i] = pts[(size_t)j * 3 + 1];
-                sz[i] = pts[(size_t)j * 3 + 2];
+    if (R <= MAXROWS) {
+        // ---- row table: every (y,z) row of cells is one contiguous range of the sorted array; the rows are laid end
+        //      to end into ONE flat candidate sequence so that all 64 lanes and QU loads per lane stay busy.  Lane k
+        //      keeps row k's flat end offset (pe) and its sorted-array offset minus its flat start (rs); a 64-candidate
+        //      chunk finds its rows with wave-uniform readlanes (no LDS, no per-lane search).
+        int s_r = 0, len = 0;
+        if (lane < R) {
+            const int cz = zlo + lane / ny, cy = ylo + lane % ny;
+            const int rowc = (cz * dy + cy) * dx;
+            s_r = start[rowc + xlo];
+            len = start[rowc + xhi + 1] - s_r;
+        }
+        const int inc = bx_wave_incl_scan_dpp(len);
+        const int T = __builtin_amdgcn_readlane(inc, 63);
+        const int rs = s_r - (inc - len);
+        const int pe = lane < R ? inc : 0x7fffffff;
+        wave_sync();
+        BX_TR(2);
+        if (tr) td[7] = T;
+        int rb = 0;                                         // wave-uniform: first row whose end lies beyond the chunk start
+        for (int v0 = 0; v0 < T; v0 += 64 * QU) {
+            float4 c[QU];
+#pragma unroll
+            for (int u = 0; u < QU; ++u) {
+                const int vc = v0 + u * 64;                 // uniform chunk start
+                const int v = vc + lane;
+                c[u] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);   // never a hit (d2 = inf)
+                if (vc < T) {                               // uniform
+                    while (__builtin_amdgcn_readlane(pe, rb) <= vc) ++rb;
+                    int addr = __builtin_amdgcn_readlane(rs, rb) + v;
+                    int k = rb;
+                    int pek = __builtin_amdgcn_readlane(pe, k);
+                    while (pek <= vc + 63) {                // uniform: a row boundary falls inside this chunk
+                        const int nrs = __builtin_amdgcn_readlane(rs, k + 1);
+                        addr = v >= pek ? nrs + v : addr;
+                        ++k;
+                        pek = __builtin_amdgcn_readlane(pe, k);
+                    }
+                    if (v < T) c[u] = sorted[addr];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < QU; ++u) {
+                const float ax = qx - c[u].x, ay = qy - c[u].y, az = qz - c[u].z;
+                const float d2 = (ax * ax + ay * ay) + az * az;
+                if (d2 < r2) set_hit<LOGC>(bm32, __float_as_int(c[u].w));
             }
         }
-        __syncthreads();
-        if (!done) {
-            const int cmax = min(TILE, n - tile0);
-            for (int c0 = 0; c0 < cmax; c0 += 64) {
-                int i = c0 + lane;
-                bool hit = false;
-                if (i < cmax) {
-                    float dx = qx - sx[i], dy = qy - sy[i], dz = qz - sz[i];
-                    float d2 = (dx * dx + dy * dy) + dz * dz;
-                    hit = d2 < r2;
+    } else {
+        // degenerate geometry (cell edge << radius because of the 1024-cells-per-axis floor): plain nested walk
+        wave_sync();
+        for (int cz = zlo; cz <= zhi; ++cz)
+            for (int cy = ylo; cy <= yhi; ++cy) {
+                const int rowc = (cz * dy + cy) * dx;
+                const int s = start[rowc + xlo], e = start[rowc + xhi + 1];
+                for (int k = s + lane; k < e; k += 64) {
+                    const float4 a = sorted[k];
+                    const float ax = qx - a.x, ay = qy - a.y, az = qz - a.z;
+                    const float d2 = (ax * ax + ay * ay) + az * az;
+                    if (d2 < r2) set_hit<LOGC>(bm32, __float_as_int(a.w));
                 }
-                unsigned long long mask = __ballot(hit);
-                int w = (tile0 + c0) >> 6;
-                if (lane == (w & 63)) myword = mask;
-                total += __popcll(mask);
-                wused = w + 1;
-                bool last = (total >= P) || (tile0 + c0 + 64 >= n);
-                if ((w & 63) == 63 || last) {
-                    int wb = w & ~63;
-                    if (wb + lane < W64) bm[wb + lane] = myword;
-                    myword = 0;
-                }
-                if (total >= P) { done = true; break; }
             }
-        }
-        if (__syncthreads_and(done ? 1 : 0)) break;
     }
-    if (q >= K) return;
+    wave_sync();
+    BX_TR(3);
 
-    // ---- popcount prefix over the visited words
-    int run = 0;
-    for (int g0 = 0; g0 < wused; g0 += 64) {
-        int w = g0 + lane;
-        unsigned long long word = w < wused ? bm[w] : 0ULL;
-        int pc = __popcll(word);
-        int ex = bx_wave_excl_scan(pc, lane);
-        if (w < wused) pf[w] = run + ex;
-        run += bx_wave_sum_i(pc);
+    // ---- ordered expansion of the first P set bits: lane l owns indices [l*64C, (l+1)*64C); its words move to
+    //      registers, then the index list is written over the bitmap
+    unsigned long long word[C];
+    int tot = 0;
+#pragma unroll
+    for (int s = 0; s < C; ++s) { word[s] = bm64[s * 64 + lane]; tot += __popcll(word[s]); }
+    const int inc = bx_wave_incl_scan_dpp(tot);
+    const int run = __builtin_amdgcn_readlane(inc, 63);
+    wave_sync();                                            // every lane has read its bitmap words
+    int pos = inc - tot;
+    if (tot > 0 && pos < P) {
+#pragma unroll
+        for (int s = 0; s < C; ++s) {
+            unsigned long long w = word[s];
+            const int base = ((lane << LOGC) + s) << 6;
+            while (w != 0ULL && pos < P) {
+                const int b = __ffsll((long long)w) - 1;
+                list[pos++] = base + b;
+                w &= w - 1ULL;
+            }
+        }
     }
     const int nhit = run < P ? run : P;
+    wave_sync();
+    BX_TR(4);
 
-    // ---- ordered expansion
-    int first = 0;
-    for (int j0 = 0; j0 < P; j0 += 64) {
-        int j = j0 + lane;
-        int idx = 0;
-        if (j < nhit) {
-            int lo = 0, hi = wused;  // first word with pf > j
-            while (lo < hi) {
-                int mid = (lo + hi) >> 1;
-                if (pf[mid] > j) hi = mid; else lo = mid + 1;
-            }
-            int w = lo - 1;
-            idx = w * 64 + select_bit(bm[w], j - pf[w]);
+    // ---- output: gather + mask arithmetic (models/patch_embedder.py:105-111), 768 contiguous bytes per wave store
+    const int first = nhit > 0 ? list[0] : 0;
+    F3* out3 = reinterpret_cast<F3*>(patches) + (size_t)q * P;
+    int32_t* outi = idx_out ? idx_out + (size_t)q * P : nullptr;
+    constexpr int OU = 8;
+    for (int j0 = 0; j0 < P; j0 += 64 * OU) {
+        int idx[OU];
+        float4 p[OU];
+#pragma unroll
+        for (int u = 0; u < OU; ++u) {
+            const int j = j0 + u * 64 + lane;
+            idx[u] = j < nhit ? list[j] : first;
         }
-        if (j0 == 0) first = __shfl(idx, 0, 64);
-        if (j >= nhit) idx = first;
-        if (j < P) {
-            float mask = (idx == first) ? 1.0f : 0.0f;
-            if (j == 0) mask = 0.0f;
-            if (j == P - 1) mask = 1.0f;
-            float om = 1.0f - mask;
-            float p0 = pts[(size_t)idx * 3 + 0], p1 = pts[(size_t)idx * 3 + 1], p2 = pts[(size_t)idx * 3 + 2];
-            size_t o = ((size_t)q * P + j);
-            if (idx_out) idx_out[o] = idx;
-            patches[o * 3 + 0] = p0 * om + qx * mask;
-            patches[o * 3 + 1] = p1 * om + qy * mask;
-            patches[o * 3 + 2] = p2 * om + qz * mask;
+#pragma unroll
+        for (int u = 0; u < OU; ++u) p[u] = pts4[idx[u]];
+#pragma unroll
+        for (int u = 0; u < OU; ++u) {
+            const int j = j0 + u * 64 + lane;
+            if (j < P) {
+                float mask = (idx[u] == first) ? 1.0f : 0.0f;
+                if (j == 0) mask = 0.0f;
+                if (j == P - 1) mask = 1.0f;
+                const float om = 1.0f - mask;
+                F3 o;
+                o.x = p[u].x * om + qx * mask;
+                o.y = p[u].y * om + qy * mask;
+                o.z = p[u].z * om + qz * mask;
+                out3[j] = o;
+                if (outi) outi[j] = idx[u];
+            }
         }
     }
+    BX_TR(5);
+    if (tr) { __builtin_amdgcn_s_waitcnt(0); td[6] = __builtin_readcyclecounter() - t0; }
+}
+
+template <int LOGC>
+int launch_query(bx_ctx* c, hipStream_t s, int K, const float* kpts, const double* radius, int P, int32_t* idx_out, float* patches_out)
+{
+    const size_t bm = ((size_t)64 << LOGC) * 8, li = (size_t)P * 4;
+    const size_t lds = (bm > li ? bm : li) * QW;
+    if (lds > 160 * 1024) { bx_set_error("bxk_ball_group: P=%d needs %zu B of LDS per keypoint (> 160 KiB)", P, lds); return BX_ERR_ARG; }
+    if (lds > 64 * 1024 && !(c->ball_attr_set & (1 << LOGC))) {
+        BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_kernel<LOGC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        c->ball_attr_set |= 1 << LOGC;
+    }
+    hipLaunchKernelGGL(ball_query_kernel<LOGC>, dim3((K + QW - 1) / QW), dim3(64 * QW), lds, s, c->ball_sorted, c->ball_start, c->ball_grid, c->ball_pts4, kpts, K,
+                       radius, P, idx_out, patches_out, c->skip, getenv("BX_BALL_DEBUG") ? c->ball_dbg : nullptr);
+    BX_LAUNCH_CHECK();
+    return BX_OK;
 }
 }  // namespace
+
+int bx_ball_div()
+{
+    static int v = 0;
+    if (!v) {
+        const char* e = getenv("BX_BALL_DIV");
+        int d = e ? atoi(e) : 3;
+        v = d < 1 ? 1 : (d > 3 ? 3 : d);
+    }
+    return v;
+}
 
 int bx_permute_launch(hipStream_t s, const float* pts, const int32_t* perm, int n, float* out, const int32_t* skip)
 {
@@ -176,19 +491,28 @@ int bxk_ball_group(bx_ctx* c, hipStream_t s, const float* pts_perm, int n, const
 {
     if (K <= 0) return BX_OK;
     if (n <= 0 || P < 2) { bx_set_error("bxk_ball_group: n=%d P=%d", n, P); return BX_ERR_ARG; }
-    const size_t W64 = ((size_t)n + 63) >> 6;
-    auto lds = [&](int wpb) { return (size_t)3 * TILE * 4 + (size_t)wpb * W64 * 12; };
-    const size_t cap = 150 * 1024;
-    if (lds(8) <= cap) {
-        hipLaunchKernelGGL(ball_group_kernel<8>, dim3((K + 7) / 8), dim3(512), lds(8), s, pts_perm, n, kpts, K, radius, P, idx_out, patches_out, c->skip);
-    } else if (lds(4) <= cap) {
-        hipLaunchKernelGGL(ball_group_kernel<4>, dim3((K + 3) / 4), dim3(256), lds(4), s, pts_perm, n, kpts, K, radius, P, idx_out, patches_out, c->skip);
-    } else if (lds(1) <= cap) {
-        hipLaunchKernelGGL(ball_group_kernel<1>, dim3(K), dim3(64), lds(1), s, pts_perm, n, kpts, K, radius, P, idx_out, patches_out, c->skip);
-    } else {
-        bx_set_error("bxk_ball_group: cloud of %d points too large for the LDS bitmap", n);
-        return BX_ERR_ARG;
+    if (n > c->p.max_points) { bx_set_error("bxk_ball_group: n=%d exceeds the context's max_points=%d", n, c->p.max_points); return BX_ERR_ARG; }
+    int logc = 3;
+    while (((size_t)64 << logc) * 64 < (size_t)n) ++logc;   // 64 lanes x C words x 64 bits >= n
+    if (logc > 8) { bx_set_error("bxk_ball_group: cloud of %d points exceeds the 1M-point bitmap", n); return BX_ERR_ARG; }
+    const int nb = (n + 255) / 256;
+    const int nb4k = (n + 1024 * COUNT_PPT - 1) / (1024 * COUNT_PPT);
+    const int ntile = BX_BALL_NCELL / SCAN_TILE + 1;
+    const int32_t* skip = c->skip;
+    hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, s, c->ball_bbox, skip);
+    hipLaunchKernelGGL(bbox_kernel, dim3(nb4k < 64 ? nb4k : 64), dim3(1024), 0, s, pts_perm, n, c->ball_bbox, skip);
+    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(64), 0, s, c->ball_bbox, radius, bx_ball_div(), c->ball_grid, skip);
+    BX_HIP(hipMemsetAsync(c->ball_cnt, 0, sizeof(int32_t) * (size_t)ntile * SCAN_TILE, s));
+    hipLaunchKernelGGL(cell_count_kernel, dim3(nb4k), dim3(1024), 0, s, pts_perm, n, c->ball_grid, c->ball_cnt, c->ball_cellrank, c->ball_pts4, skip);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(ntile), dim3(256), 0, s, c->ball_cnt, c->ball_grid, c->ball_bsum, skip);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(ntile), dim3(256), 0, s, c->ball_cnt, c->ball_grid, c->ball_bsum, c->ball_start, skip);
+    hipLaunchKernelGGL(cell_scatter_kernel, dim3(nb), dim3(256), 0, s, c->ball_pts4, n, c->ball_cellrank, c->ball_start, c->ball_sorted, skip);
+    switch (logc) {
+    case 3: return launch_query<3>(c, s, K, kpts, radius, P, idx_out, patches_out);
+    case 4: return launch_query<4>(c, s, K, kpts, radius, P, idx_out, patches_out);
+    case 5: return launch_query<5>(c, s, K, kpts, radius, P, idx_out, patches_out);
+    case 6: return launch_query<6>(c, s, K, kpts, radius, P, idx_out, patches_out);
+    case 7: return launch_query<7>(c, s, K, kpts, radius, P, idx_out, patches_out);
+    default: return launch_query<8>(c, s, K, kpts, radius, P, idx_out, patches_out);
     }
-    BX_LAUNCH_CHECK();
-    return BX_OK;
 }

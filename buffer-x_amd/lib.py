@@ -40,7 +40,7 @@ class BxResult(C.Structure):
 
 
 EXPORTS = ["bx_create", "bx_destroy", "bx_last_error", "bx_load_weights", "bx_workspace_bytes", "bx_register_pair",
-           "bx_profile_enable", "bx_profile_read",
+           "bx_profile_enable", "bx_profile_read", "bx_debug_read",
            "bx_fps", "bx_radius", "bx_permute", "bx_ball_group", "bx_patch_features", "bx_desc_net", "bx_conv_layer",
            "bx_mutual", "bx_pose_net", "bx_hypotheses", "bx_consensus", "bx_ransac", "bx_refine"]
 

@@ -115,6 +115,9 @@ int64_t bx_workspace_bytes(const bx_ctx *ctx);
 #define BX_PROF_TAGS 16
 int bx_profile_enable(bx_ctx *ctx, int32_t on);
 int bx_profile_read(bx_ctx *ctx, double *ms_out, int32_t *count_out);
+/* diagnostics: in-kernel cycle stamps of the neighbour-gather query kernel (collected when the environment
+ * variable BX_BALL_DEBUG is set): up to 64 records of 8 int64 {t0, setup, rows, scan, expand, output, drained, T}. */
+int bx_debug_read(bx_ctx *ctx, int64_t *out, int32_t n);
 
 /* ---- whole pair: replaces BufferX.forward's inference branch, models/BUFFERX.py:257-467 -------
  * src/tgt: device float32 [n][3].  perm_src/perm_tgt: device int32 permutations, one per scale

@@ -81,6 +81,77 @@ def test_ball_group_exact(ctx, oracle, bx, n, K, P, r):
     assert np.array_equal(_np(patches), rpatches)
 
 
+@pytest.mark.parametrize("case", ["outdoor", "far_queries", "tiny_radius", "huge_radius", "offset_cloud", "flat", "dup_points", "n63"])
+def test_ball_group_grid_edges(ctx, oracle, bx, case):
+    """Edge cases of the uniform-grid candidate search: the result must stay the brute-force first-P list."""
+    import torch
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(case.encode()) % 1000)
+    P, r = 64, 0.3
+    if case == "outdoor":          # large extent / small radius => cell edge grows beyond r (cell budget)
+        pts = bx.synth.make_pair(4, "outdoor", n_target=40000)["src"]
+        kp = pts[oracle.fps(pts, 128)]
+        r = 0.4
+    elif case == "far_queries":    # keypoints outside the cloud's bounding box (clamped cell ranges)
+        pts = rng.random((4000, 3), np.float32)
+        kp = np.concatenate([rng.random((32, 3), np.float32) * 3 - 1, pts[:32] + np.float32(0.29)]).astype(np.float32)
+    elif case == "tiny_radius":    # most keypoints only hit themselves
+        pts = rng.random((6000, 3), np.float32)
+        kp = pts[:100].copy()
+        r = 1e-3
+    elif case == "huge_radius":    # every point is a hit: first-P truncation, 1-cell grid
+        pts = rng.random((3000, 3), np.float32)
+        kp = pts[:50].copy()
+        r = 10.0
+    elif case == "offset_cloud":   # large coordinates: rounding of q -+ r and of the cell map
+        pts = (rng.random((8000, 3), np.float32) * 2 + np.float32([1000, -2000, 500])).astype(np.float32)
+        kp = pts[::80].copy()
+        r = 0.25
+    elif case == "flat":           # zero extent along z
+        pts = rng.random((5000, 3), np.float32)
+        pts[:, 2] = 0.5
+        kp = pts[::50].copy()
+        r = 0.1
+    elif case == "dup_points":     # identical points (same cell, same distance)
+        base = rng.random((500, 3), np.float32)
+        pts = np.repeat(base, 8, axis=0)[rng.permutation(4000)]
+        kp = base[:64].copy()
+        r = 0.15
+    else:                          # n not a multiple of 64 and smaller than a wave
+        pts = rng.random((63, 3), np.float32)
+        kp = pts[:10].copy()
+        r = 0.5
+    pts = np.ascontiguousarray(pts, np.float32)
+    idx, patches = ctx.ball_group(pts, kp, torch.tensor([r], dtype=torch.float64), P)
+    ridx, rp = oracle.ball_group(pts, kp, np.float32(r), P)
+    assert np.array_equal(_np(idx), ridx)
+    assert np.array_equal(_np(patches), rp)
+
+
+def test_ball_group_boundary_distances(ctx, oracle):
+    """Points at distance r(1 +- few ulp) from the keypoint along each axis, with the keypoint next to a cell face:
+    the strict fp32 test decides, never the grid."""
+    import torch
+    rng = np.random.default_rng(9)
+    r = np.float32(0.25)
+    kp = (rng.random((64, 3), np.float32) * 2).astype(np.float32)
+    pts = [rng.random((2000, 3), np.float32) * 2]
+    for ax in range(3):
+        for sgn in (-1, 1):
+            for ulps in (-3, -1, 0, 1, 3):
+                d = r
+                for _ in range(abs(ulps)):
+                    d = np.nextafter(d, np.float32(1e9 if ulps > 0 else 0), dtype=np.float32)
+                q = kp.copy()
+                q[:, ax] = q[:, ax] + np.float32(sgn) * d
+                pts.append(q)
+    pts = np.concatenate(pts).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    idx, patches = ctx.ball_group(pts, kp, torch.tensor([float(r)], dtype=torch.float64), 128)
+    ridx, rp = oracle.ball_group(pts, kp, r, 128)
+    assert np.array_equal(_np(idx), ridx) and np.array_equal(_np(patches), rp)
+
+
 def test_ball_group_no_hits(ctx, oracle):
     import torch
     rng = np.random.default_rng(1)
