@@ -17,6 +17,7 @@
 // wave (wm, wn) owns output tiles {wm + t*WM} x 16 channels with fp32 accumulators in VGPRs, weights
 // stream from L2 as B fragments (one dword per lane per MFMA, reused across the wave's tiles).
 #include "bx_common.h"
+#include <cstdlib>
 
 namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -36,12 +37,20 @@ struct ConvCfg {
     static constexpr int NBUF = DB ? 2 : 1;
     static constexpr int NLD = (ROWS * 4 + CT - 1) / CT;
     static constexpr size_t LDS_BYTES = (size_t)NBUF * BUF_FLOATS * 4 + (size_t)NTAPS * MT * 16 * 2;
+    // register budget: two co-resident workgroups (4 waves/SIMD, <= 128 VGPRs) whenever the accumulator tile allows it
+    static constexpr int MINW = (LDS_BYTES <= 80 * 1024 && (TPW <= 10 || P_IN == 140)) ? 4 : 2;
+    // fat accumulator tiles: no one-tap-ahead row-offset registers / pinned A pairs (they would cost the second workgroup)
+    static constexpr bool LEAN = TPW > 10;
     static_assert(NT == 2 || NT == 4 || NT == 8, "COUT must give 2/4/8 column tiles");
     static_assert(ROWS + 1 < 65536, "row table is u16");
 };
 
+// Persistent workgroups: workgroup b walks the unit groups b, b + gridDim.x, ... and treats (group, chunk) as ONE flat
+// sequence of input slabs: while slab s is on the matrix cores, slab s+1 (the next chunk, or chunk 0 of the NEXT group)
+// is already in flight from HBM, so neither the per-group prologue (row table, first load) nor the epilogue stores
+// leave the MFMA pipe idle.  The row table depends only on the layer geometry and is built once per workgroup.
 template <int NCHUNK, int NTAPS, int P_IN, int P_OUT, int COUT, int G, bool RELU, bool DB>
-__global__ __launch_bounds__(CT) void conv_kernel(const float* __restrict__ in, const int32_t* __restrict__ units_dev,
+__global__ __launch_bounds__(CT, (ConvCfg<NCHUNK, NTAPS, P_IN, P_OUT, COUT, G, RELU, DB>::MINW)) void conv_kernel(const float* __restrict__ in, const int32_t* __restrict__ units_dev,
                                                   int max_units, const float* __restrict__ W, const float* __restrict__ bias,
                                                   const int32_t* __restrict__ tap, float* __restrict__ out,
                                                   const int32_t* __restrict__ skip)
@@ -54,24 +63,23 @@ __global__ __launch_bounds__(CT) void conv_kernel(const float* __restrict__ in, 
 
     int units = max_units;
     if (units_dev) { int u = *units_dev; units = u < max_units ? u : max_units; }
-    const int u0 = blockIdx.x * G;
-    if (u0 >= units) return;
-    const int gcount = (units - u0) < G ? (units - u0) : G;
+    const int ngroups = (units + G - 1) / G;
+    if ((int)blockIdx.x >= ngroups) return;
+    const int my_groups = (ngroups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nslabs = my_groups * NCHUNK;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave % C::WN, wm = wave / C::WN;
     const int li = lane & 15, kk = lane >> 4;
 
-    // ---- row-offset table (geometry + padding), zero rows
+    // ---- row-offset table (geometry + padding; rows of units beyond the tail group are loaded as zeros), zero rows
     for (int idx = tid; idx < NTAPS * C::MT * 16; idx += CT) {
         int tp = idx / (C::MT * 16), m = idx - tp * (C::MT * 16);
         int r = C::ROWS;
         if (m < C::M) {
             int g = m / P_OUT, pos = m - g * P_OUT;
-            if (g < gcount) {
-                int ip = tap[tp * P_OUT + pos];
-                if (ip >= 0) r = g * P_IN + ip;
-            }
+            int ip = tap[tp * P_OUT + pos];
+            if (ip >= 0) r = g * P_IN + ip;
         }
         roff[idx] = (unsigned short)r;
     }
@@ -80,16 +88,18 @@ __global__ __launch_bounds__(CT) void conv_kernel(const float* __restrict__ in, 
         buf[(size_t)b * C::BUF_FLOATS + (size_t)C::ROWS * ROWF + (tid - b * ROWF)] = 0.0f;
     }
 
-    // ---- staging helpers
+    // ---- staging helpers: slab s = (group blockIdx.x + (s / NCHUNK) * gridDim.x, chunk s % NCHUNK)
     const float4* in4 = reinterpret_cast<const float4*>(in);
     float4 st[C::NLD];
-    auto gload = [&](int cc) {
+    auto gload = [&](int s_) {
+        const int gi = s_ / NCHUNK, cc = s_ - gi * NCHUNK;
+        const int u0 = ((int)blockIdx.x + gi * (int)gridDim.x) * G;
 #pragma unroll
         for (int q = 0; q < C::NLD; ++q) {
             int f = tid + q * CT;
             int row = f >> 2, part = f & 3;
             int g = row / P_IN, p = row - g * P_IN;
-            if (row < C::ROWS && g < gcount)
+            if (row < C::ROWS && u0 + g < units)
                 st[q] = in4[(((size_t)(u0 + g) * NCHUNK + cc) * P_IN + p) * 4 + part];
             else
                 st[q] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -109,68 +119,151 @@ __global__ __launch_bounds__(CT) void conv_kernel(const float* __restrict__ in, 
     lwrite(0);
     __syncthreads();
 
-    // ---- accumulators start at the (BN-folded) bias
     const int n0 = wn * 16;
     const bool colok = (n0 + li) < COUT;
     const float bv = colok ? bias[n0 + li] : 0.0f;
     f32x4 acc[C::TPW];
-#pragma unroll
-    for (int t = 0; t < C::TPW; ++t) acc[t] = (f32x4){bv, bv, bv, bv};
 
-    for (int cc = 0; cc < NCHUNK; ++cc) {
-        const int cur = DB ? (cc & 1) : 0;
-        if (DB && cc + 1 < NCHUNK) gload(cc + 1);
+    // B fragments (weights, L2-resident) and the A row offsets are fetched ONE TAP AHEAD of the MFMAs that consume
+    // them, so neither the ~500-cycle L2 round trip nor the dependent LDS table read sits in front of the matrix pipe.
+    // A wave whose last tile does not exist (mt >= MT) runs it on the zero row: uniform schedule, no exec-mask branches.
+    const float* wbase = W + (size_t)kk * COUT + n0 + li;
+    auto loadB = [&](int ct, float (&b)[4]) {
+        const float* wp = wbase + (size_t)ct * 16 * COUT;
+        b[0] = colok ? wp[0] : 0.f;
+        b[1] = colok ? wp[4 * COUT] : 0.f;
+        b[2] = colok ? wp[8 * COUT] : 0.f;
+        b[3] = colok ? wp[12 * COUT] : 0.f;
+    };
+    auto loadR = [&](int tp, int (&r)[C::TPW]) {
+        const unsigned short* ro = roff + (size_t)tp * C::MT * 16 + li;
+#pragma unroll
+        for (int t = 0; t < C::TPW; ++t) {
+            const int mt = wm + t * C::WM;
+            r[t] = mt < C::MT ? (int)ro[mt * 16] : C::ROWS;
+        }
+    };
+    float bc[4], bn[4];
+    int rc[C::TPW], rn[C::TPW];
+    loadB(0, bc);
+    if constexpr (!C::LEAN) loadR(0, rc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bn[i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < C::TPW; ++t) rn[t] = C::ROWS;
+    // drain the prologue loads here: otherwise the waitcnt pass sees them pending on the loop's entry edge and
+    // waits for the NEWEST loads (the counters are in-order) in front of every tap's first MFMAs
+    __builtin_amdgcn_s_waitcnt(0);
+
+    const int slot = 4 * (li & 3) + (li >> 2);
+    int cc = 0, gi = 0;
+    for (int s_ = 0; s_ < nslabs; ++s_) {
+        const int cur = DB ? (s_ & 1) : 0;
+        if (cc == 0) {
+#pragma unroll
+            for (int t = 0; t < C::TPW; ++t) acc[t] = (f32x4){bv, bv, bv, bv};
+        }
+        if (DB && s_ + 1 < nslabs) gload(s_ + 1);
         const float* lb = buf + (size_t)cur * C::BUF_FLOATS + kk * 4;
 #pragma unroll 1
         for (int tp = 0; tp < NTAPS; ++tp) {
-            const float* wp = W + (((size_t)cc * NTAPS + tp) * 16 + kk) * COUT + n0 + li;
-            float b0 = colok ? wp[0] : 0.f;
-            float b1 = colok ? wp[4 * COUT] : 0.f;
-            float b2 = colok ? wp[8 * COUT] : 0.f;
-            float b3 = colok ? wp[12 * COUT] : 0.f;
-            const unsigned short* ro = roff + (size_t)tp * C::MT * 16 + li;
+            {
+                int ctn = cc * NTAPS + tp + 1;
+                if (ctn == NCHUNK * NTAPS) ctn = 0;      // first tap of the next group's chunk 0 (harmless after the last slab)
+                loadB(ctn, bn);
+                if constexpr (!C::LEAN) loadR(tp + 1 < NTAPS ? tp + 1 : 0, rn);
+            }
+#ifdef BX_EXP_NOLDS
+#define BX_A(r) (f32x4){(float)(r), bc[1], bc[2], bc[3]}
+#else
+#define BX_A(r) (*reinterpret_cast<const f32x4*>(lb + (size_t)(r) * ROWF))
+#endif
+            if constexpr (C::LEAN) {
+                const unsigned short* ro = roff + (size_t)tp * C::MT * 16 + li;
+#pragma unroll
+                for (int t = 0; t < C::TPW; ++t) {
+                    const int mt = wm + t * C::WM;
+                    if (mt < C::MT) {
+                        f32x4 a = BX_A((int)ro[mt * 16]);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bc[0], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bc[1], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bc[2], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bc[3], acc[t], 0, 0, 0);
+                    }
+                }
+            } else {
+            // two tiles in flight, the next pair's A operands requested before this pair's MFMAs issue
+                f32x4 a0 = BX_A(rc[0]);
+                f32x4 a1 = C::TPW > 1 ? BX_A(rc[C::TPW > 1 ? 1 : 0]) : a0;
+#pragma unroll
+                for (int t = 0; t + 1 < C::TPW; t += 2) {
+                    f32x4 n0v = a0, n1v = a1;
+                    if (t + 2 < C::TPW) n0v = BX_A(rc[t + 2 < C::TPW ? t + 2 : 0]);
+                    if (t + 3 < C::TPW) n1v = BX_A(rc[t + 3 < C::TPW ? t + 3 : 0]);
+                    // (pinning this order with sched_barrier measured 10 % SLOWER than the compiler's own schedule)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bc[0], acc[t], 0, 0, 0);
+                    acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bc[0], acc[t + 1], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bc[1], acc[t], 0, 0, 0);
+                    acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bc[1], acc[t + 1], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bc[2], acc[t], 0, 0, 0);
+                    acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bc[2], acc[t + 1], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bc[3], acc[t], 0, 0, 0);
+                    acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bc[3], acc[t + 1], 0, 0, 0);
+                    a0 = n0v; a1 = n1v;
+                }
+                if (C::TPW & 1) {
+                    constexpr int t = C::TPW - 1;
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bc[0], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bc[1], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bc[2], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bc[3], acc[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bc[i] = bn[i];
+            if constexpr (!C::LEAN) {
+#pragma unroll
+                for (int t = 0; t < C::TPW; ++t) rc[t] = rn[t];
+            }
+        }
+        if (cc == NCHUNK - 1) {
+            // ---- epilogue of this group: ReLU, store in chunk-slot order (fire-and-forget; the next slab's MFMAs follow)
+            const int u0 = ((int)blockIdx.x + gi * (int)gridDim.x) * G;
+            int mrow0 = kk * 4;
+            asm volatile("" : "+v"(mrow0));   // keeps the 4*TPW store addresses out of the loop-invariant hoisting (VGPR budget)
 #pragma unroll
             for (int t = 0; t < C::TPW; ++t) {
                 const int mt = wm + t * C::WM;
-                if (mt < C::MT) {
-                    int r = ro[mt * 16];
-                    f32x4 a = *reinterpret_cast<const f32x4*>(lb + (size_t)r * ROWF);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b2, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b3, acc[t], 0, 0, 0);
+                if (mt >= C::MT) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int m = mt * 16 + mrow0 + r;
+                    if (m < C::M) {
+                        int g = m / P_OUT, pos = m - g * P_OUT;
+                        if (u0 + g < units) {
+                            float v = acc[t][r];
+                            if (RELU) v = v > 0.0f ? v : 0.0f;
+                            out[(((size_t)(u0 + g) * C::NT + wn) * P_OUT + pos) * 16 + slot] = v;
+                        }
+                    }
                 }
             }
         }
+#ifdef BX_EXP_NOSYNC
         if (DB) {
-            if (cc + 1 < NCHUNK) lwrite(cur ^ 1);
+            if (s_ + 1 < nslabs && s_ < 0) lwrite(cur ^ 1);
+        } else
+#endif
+        if (DB) {
+            if (s_ + 1 < nslabs) lwrite(cur ^ 1);
             __syncthreads();
-        } else if (cc + 1 < NCHUNK) {
+        } else if (s_ + 1 < nslabs) {
             __syncthreads();
-            gload(cc + 1);
+            gload(s_ + 1);
             lwrite(0);
             __syncthreads();
         }
-    }
-
-    // ---- epilogue: ReLU, store in chunk-slot order
-    const int slot = 4 * (li & 3) + (li >> 2);
-#pragma unroll
-    for (int t = 0; t < C::TPW; ++t) {
-        const int mt = wm + t * C::WM;
-        if (mt >= C::MT) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int m = mt * 16 + kk * 4 + r;
-            if (m < C::M) {
-                int g = m / P_OUT, pos = m - g * P_OUT;
-                if (g < gcount) {
-                    float v = acc[t][r];
-                    if (RELU) v = v > 0.0f ? v : 0.0f;
-                    out[(((size_t)(u0 + g) * C::NT + wn) * P_OUT + pos) * 16 + slot] = v;
-                }
-            }
-        }
+        if (++cc == NCHUNK) { cc = 0; ++gi; }
     }
 }
 
@@ -284,6 +377,22 @@ int launch_conv(hipStream_t s, const ConvLayerDev& L, const float* in, const int
     }
     int grid = (max_units + G - 1) / G;
     if (grid <= 0) return BX_OK;
+    // persistent workgroups: as many as are co-resident (LDS- and register-limited), each walking its groups
+    static int wg_per_cu = 0, n_cu = 0;
+    if (!wg_per_cu) {
+        int dev = 0, occ = 0;
+        hipDeviceProp_t prop;
+        BX_HIP(hipGetDevice(&dev));
+        BX_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount;
+        BX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, CT, C::LDS_BYTES));
+        wg_per_cu = 1 << 20;   // default: one unit group per workgroup (measured faster than the persistent walk)
+        (void)occ;
+        const char* e = getenv("BX_CONV_WGPCU");
+        if (e && atoi(e) > 0) wg_per_cu = atoi(e);
+    }
+    const long long cap = (long long)wg_per_cu * n_cu;
+    if ((long long)grid > cap) grid = (int)cap;
     hipLaunchKernelGGL(k, dim3(grid), dim3(CT), C::LDS_BYTES, s, in, units_dev, max_units, L.W, L.b, L.tap, out, skip);
     BX_LAUNCH_CHECK();
     return BX_OK;
@@ -294,16 +403,19 @@ int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, cons
 {
     if (net == 0) {
         const ConvLayerDev& L = c->desc[layer];
+        // Units per workgroup chosen by measurement (tools/gpu_conv.sh, K = 5000): 64- and 32-channel layers run 2 units
+        // per workgroup (9 accumulator tiles per wave, <= 128 VGPRs, 2-3 workgroups per CU); the 128-channel layers
+        // keep 2 units (18 tiles per wave, "lean" loop) -- 1 unit per workgroup halves the reuse of the B fragments.
         switch (layer) {
             //                     NCHUNK taps P_IN P_OUT COUT G  RELU  DB
-            case 0: return launch_conv<3, 9, 140, 140, 64, 4, true, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 1: return launch_conv<4, 9, 140, 140, 64, 4, true, true>(s, L, in, units_dev, max_units, out, c->skip);
+            case 0: return launch_conv<3, 9, 140, 140, 64, 2, true, true>(s, L, in, units_dev, max_units, out, c->skip);
+            case 1: return launch_conv<4, 9, 140, 140, 64, 2, true, true>(s, L, in, units_dev, max_units, out, c->skip);
             case 2: return launch_conv<4, 9, 140, 140, 128, 2, true, true>(s, L, in, units_dev, max_units, out, c->skip);
             case 3: return launch_conv<8, 9, 140, 140, 128, 2, true, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 4: return launch_conv<8, 9, 140, 140, 64, 4, true, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 5: return launch_conv<4, 9, 140, 140, 64, 4, true, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 6: return launch_conv<4, 9, 140, 140, 32, 4, true, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 7: return launch_conv<2, 9, 140, 140, 32, 4, false, true>(s, L, in, units_dev, max_units, out, c->skip);
+            case 4: return launch_conv<8, 9, 140, 140, 64, 2, true, true>(s, L, in, units_dev, max_units, out, c->skip);
+            case 5: return launch_conv<4, 9, 140, 140, 64, 2, true, true>(s, L, in, units_dev, max_units, out, c->skip);
+            case 6: return launch_conv<4, 9, 140, 140, 32, 2, true, true>(s, L, in, units_dev, max_units, out, c->skip);
+            case 7: return launch_conv<2, 9, 140, 140, 32, 2, false, true>(s, L, in, units_dev, max_units, out, c->skip);
         }
     } else if (net == 1) {
         const ConvLayerDev& L = c->pose[layer];

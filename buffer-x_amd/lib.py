@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_SO = os.path.join(_CSRC, "libbufferx_hip.so")
+_SO = os.environ.get("BX_HIP_SO") or os.path.join(_CSRC, "libbufferx_hip.so")   # BX_HIP_SO: kernel-experiment builds (tools/)
 _LIB = None
 
 BX_MAX_SCALES = 8
