@@ -108,15 +108,18 @@ void carve(bx_ctx* c, char* base, size_t* total)
 
 // host restatement of get_voxel_coordinate / var_to_invar tables (reference utils/common.py:248-262, 390-405,
 // 422-428, 483-493, 117-128): binary64 libm like numpy, then rounded to fp32 like torch.FloatTensor.
-void voxel_tables(std::vector<float>& cen, std::vector<float>& rot)
+void voxel_tables(std::vector<float>& cen, std::vector<float>& rot, std::vector<float>& rowc)
 {
     const double PI = 3.14159265358979323846;
     cen.resize((size_t)BX_VOX * 3);
     rot.resize((size_t)BX_AZI * 4);
+    rowc.resize((size_t)BX_RAD * BX_ELE * 2);
     for (int s = 0; s < BX_RAD; ++s) {
         double scale = (double)s / (double)BX_RAD + 1.0 / (double)(2 * BX_RAD);
         for (int e = 0; e < BX_ELE; ++e) {
             double beta = (double)e * (PI / (double)BX_ELE) + PI / (double)BX_ELE / 2.0;
+            rowc[(size_t)(s * BX_ELE + e) * 2] = (float)(scale * std::sin(beta));
+            rowc[(size_t)(s * BX_ELE + e) * 2 + 1] = (float)(scale * std::cos(beta));
             for (int a = 0; a < BX_AZI; ++a) {
                 double alpha = (double)a * (2.0 * PI / (double)BX_AZI) + PI / (double)BX_AZI;
                 double x = std::sin(beta) * std::cos(alpha), y = std::sin(beta) * std::sin(alpha), z = std::cos(beta);
@@ -296,11 +299,12 @@ int bx_create(int device_id, const bx_params* params, bx_ctx** out)
     carve(c, c->arena, &total);
     BX_HIP(hipMemset(c->state, 0, sizeof(PairState)));
     BX_HIP(hipMemset(c->err_flag, 0, 4 * sizeof(int32_t)));
-    std::vector<float> cen, rot;
-    voxel_tables(cen, rot);
+    std::vector<float> cen, rot, rowc;
+    voxel_tables(cen, rot, rowc);
     int rc;
     if ((rc = upload(&c->d_centres, cen.data(), cen.size())) != BX_OK) return rc;
     if ((rc = upload(&c->d_rot, rot.data(), rot.size())) != BX_OK) return rc;
+    if ((rc = upload(&c->d_rowc, rowc.data(), rowc.size())) != BX_OK) return rc;
     std::vector<float> thr(8193);
     for (int m = 0; m <= 8192; ++m) {
         // the bisection of models/BUFFERX.py:675-692 only visits des_r = 5 m / 8192; compare value = fp32(des_r*des_r)
@@ -318,7 +322,7 @@ int bx_destroy(bx_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(c->arena);
-    (void)hipFree(c->d_centres); (void)hipFree(c->d_rot); (void)hipFree(c->d_rad_thr);
+    (void)hipFree(c->d_centres); (void)hipFree(c->d_rot); (void)hipFree(c->d_rowc); (void)hipFree(c->d_rad_thr);
     (void)hipFree(c->d_pnt_w); (void)hipFree(c->d_pnt_b); (void)hipFree(c->d_pool_w1); (void)hipFree(c->d_pool_b1); (void)hipFree(c->d_pool_w2); (void)hipFree(c->d_pool_b2);
     for (int i = 0; i < BX_NDESC; ++i) { (void)hipFree(c->desc[i].W); (void)hipFree(c->desc[i].b); (void)hipFree(c->desc[i].tap); }
     for (int i = 0; i < BX_NPOSE; ++i) { (void)hipFree(c->pose[i].W); (void)hipFree(c->pose[i].b); (void)hipFree(c->pose[i].tap); }

@@ -73,6 +73,8 @@ struct bx_ctx {
     // constants
     float* d_centres;   // [420][3]
     float* d_rot;       // [20][4]
+    float* d_rowc;      // [21][2] circle {radius, height} of every (shell, elevation) row of voxel centres
+    int patch_attr_set;
     float* d_rad_thr;   // [8193] radius-estimation thresholds (float)(r_m^2)
     float *d_pnt_w, *d_pnt_b, *d_pool_w1, *d_pool_b1, *d_pool_w2, *d_pool_b2;
     ConvLayerDev desc[BX_NDESC];

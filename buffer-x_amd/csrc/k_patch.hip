@@ -1,144 +1,230 @@
-// k_patch.hip -- patch -> cylindrical voxel features, one workgroup per patch, fused:
+// k_patch.hip -- patch -> cylindrical voxel features, fused:
 //   axis_align   (reference models/patch_embedder.py:122-148; utils/common.py:709-726 cal_Z_axis,
 //                 :501-525 RodsRotatFormula, :111-114 l2_norm)
 //   normalize    (models/patch_embedder.py:167-170)
 //   SPT          (models/patch_embedder.py:150-165; utils/common.py:431-469 sphere_query, :472-498 var_to_invar)
 //   pnt_layer + max over the voxel samples (models/patch_embedder.py:26-30, 73-77)
 // The reference materialises [K,P,3] x4 temporaries, a [K,420,10,3] gather, the constant voxel grid and 20
-// rotation matrices per call; here the patch lives in LDS (16 B/point), the 3x3 covariance is a wave
-// reduction (xor-butterfly, the arithmetic contract's "wave order"), the eigenvector comes from a binary64
-// Jacobi on one wave, and each thread owns voxels: it scans the patch in order with LDS broadcast reads,
-// keeps the first `voxel_sample` hits, and applies mask, azimuth de-rotation, 3->16 conv + ReLU and the max
-// in registers.  Output: feat [K][rad][ele*azi][16] in chunk-slot order (bx_chunk_slot).
+// rotation matrices per call.  Two kernels here:
+//   patch_axis_kernel      one WAVE per patch: 3x3 covariance (lane-strided fmaf partials + xor butterfly, the
+//                          arithmetic contract's "wave order"), binary64 Jacobi eigenvector, Rodrigues -> R [K][9].
+//                          The Jacobi is a ~40k-cycle serial chain; as its own kernel with 32 waves per CU it is
+//                          hidden by parallelism instead of stalling the other waves of a patch's workgroup.
+//   patch_features_kernel  one 512-thread workgroup per patch: the patch lives in LDS (16 B/point: x, y, z, and the
+//                          cylindrical radius); candidate lists per (shell, elevation) row by ballot compaction; a
+//                          wave owns 3 rows (60 voxels) and scans the rows' lists 8 candidates per step with LDS
+//                          broadcast reads; mask, azimuth de-rotation, 3->16 conv + ReLU and the max in registers.
+// Output: feat [K][rad][ele*azi][16] in chunk-slot order (bx_chunk_slot).
 #include "bx_common.h"
+#include <cstdlib>
 
 namespace {
-constexpr int PF_THREADS = 256;
+constexpr int PF_THREADS = 512;
+constexpr int PF_WAVES = PF_THREADS / 64;
 constexpr int MAX_NS = 16;
+constexpr int NROWS = BX_RAD * BX_ELE;                 // 21 (shell, elevation) rows of BX_AZI voxels
+constexpr int RPW = (NROWS + PF_WAVES - 1) / PF_WAVES;   // candidate-list rows built per wave (3)
+
+__global__ __launch_bounds__(256) void patch_axis_kernel(const float* __restrict__ patches, int K, int P, float* __restrict__ R_out,
+                                                         const int32_t* __restrict__ skip)
+{
+    if (skip && *skip) return;
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= K) return;
+    const float* pp = patches + (size_t)q * P * 3;
+    const float cx = pp[(size_t)(P - 1) * 3], cy = pp[(size_t)(P - 1) * 3 + 1], cz = pp[(size_t)(P - 1) * 3 + 2];
+    float c00 = 0.f, c01 = 0.f, c02 = 0.f, c11 = 0.f, c12 = 0.f, c22 = 0.f;
+    for (int i = lane; i < P; i += 64) {
+        const float dx = pp[(size_t)i * 3] - cx, dy = pp[(size_t)i * 3 + 1] - cy, dz = pp[(size_t)i * 3 + 2] - cz;
+        c00 = fmaf(dx, dx, c00); c01 = fmaf(dx, dy, c01); c02 = fmaf(dx, dz, c02);
+        c11 = fmaf(dy, dy, c11); c12 = fmaf(dy, dz, c12); c22 = fmaf(dz, dz, c22);
+    }
+    c00 = bx_wave_sum(c00); c01 = bx_wave_sum(c01); c02 = bx_wave_sum(c02);
+    c11 = bx_wave_sum(c11); c12 = bx_wave_sum(c12); c22 = bx_wave_sum(c22);
+    double A[9] = {(double)c00, (double)c01, (double)c02, (double)c01, (double)c11, (double)c12,
+                   (double)c02, (double)c12, (double)c22};
+    double V[9], w[3];
+    bxd_jacobi3(A, V, w);
+    int mi = 0;
+    double mv = fabs(w[0]);
+    if (fabs(w[1]) < mv) { mv = fabs(w[1]); mi = 1; }
+    if (fabs(w[2]) < mv) { mv = fabs(w[2]); mi = 2; }
+    float z0 = (float)(mi == 0 ? V[0] : (mi == 1 ? V[1] : V[2]));
+    float z1 = (float)(mi == 0 ? V[3] : (mi == 1 ? V[4] : V[5]));
+    float z2 = (float)(mi == 0 ? V[6] : (mi == 1 ? V[7] : V[8]));
+    float sdot = ((-z0) * cx + (-z1) * cy) + (-z2) * cz;
+    if (sdot < 0.0f) { z0 = -z0; z1 = -z1; z2 = -z2; }
+    float nz = sqrtf((z0 * z0 + z1 * z1) + z2 * z2);
+    z0 = z0 / nz; z1 = z1 / nz; z2 = z2 / nz;
+    float c0 = z1, c1 = -z0, c2 = 0.0f;
+    float na = sqrtf((z0 * z0 + z1 * z1) + z2 * z2);
+    float nae = na > 1e-8f ? na : 1e-8f;
+    float cosv = z2 / nae;
+    float theta = (float)bxd_acos((double)cosv);
+    double sd, cd;
+    bxd_sincos((double)theta, &sd, &cd);
+    float sn = (float)sd, cs = (float)cd;
+    float nc = sqrtf((c0 * c0 + c1 * c1) + c2 * c2);
+    float nce = nc > 1e-12f ? nc : 1e-12f;
+    c0 = c0 / nce; c1 = c1 / nce; c2 = c2 / nce;
+    float Rx[9] = {0.0f, -c2, c1, c2, 0.0f, -c0, -c1, c0, 0.0f};
+    float Rx2[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            Rx2[i * 3 + j] = fmaf(Rx[i * 3 + 2], Rx[2 * 3 + j], fmaf(Rx[i * 3 + 1], Rx[1 * 3 + j], Rx[i * 3 + 0] * Rx[0 * 3 + j]));
+    float omc = 1.0f - cs;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float I = (i == j) ? 1.0f : 0.0f;
+                float rr = (I + sn * Rx[i * 3 + j]) + omc * Rx2[i * 3 + j];
+                R_out[(size_t)q * 9 + j * 3 + i] = rr;  // transpose(-1,-2)
+            }
+    }
+}
 
 __global__ __launch_bounds__(PF_THREADS) void patch_features_kernel(
     const float* __restrict__ patches, int K, int P, const double* __restrict__ radius, int aligned,
-    const float* __restrict__ centres, const float* __restrict__ rot, int nsample, float voxel_r,
+    const float* __restrict__ centres, const float* __restrict__ rowc, const float* __restrict__ rot, int nsample, float voxel_r,
     const float* __restrict__ pnt_w, const float* __restrict__ pnt_b, float* __restrict__ R_out, float* __restrict__ feat,
-    const int32_t* __restrict__ skip)
+    const int32_t* __restrict__ skip, int cap, long long* __restrict__ dbg)
 {
     if (skip && *skip) return;
+    // optional cycle stamps (BX_BALL_DEBUG): {t0, normalised, row lists, query of wave 0, conv+store of wave 0}
+    long long t0 = 0;
+    const bool tr = dbg != nullptr && (blockIdx.x % 79) == 0 && blockIdx.x / 79 < 60 && threadIdx.x == 0;
+    long long* td = dbg + (blockIdx.x / 79) * 8;
+    if (tr) { t0 = __builtin_readcyclecounter(); td[0] = t0; }
+#define PF_TR(k) do { if (tr) td[k] = __builtin_readcyclecounter() - t0; } while (0)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* sp = reinterpret_cast<float4*>(smem);                            // [P]
-    unsigned short* shit = reinterpret_cast<unsigned short*>(sp + P);       // [nsample][BX_VOX]
-    float* sR = reinterpret_cast<float*>(shit + (size_t)MAX_NS * BX_VOX);   // [9] (+pad)
+    float4* sp = reinterpret_cast<float4*>(smem);                             // [P] x, y, z, sqrt(x^2 + y^2)
+    unsigned short* shit = reinterpret_cast<unsigned short*>(sp + P);        // [nsample][BX_VOX]
+    int* rlen = reinterpret_cast<int*>(shit + (size_t)nsample * BX_VOX);     // [32] candidates per (shell, elevation) row
+    unsigned short* rlist = reinterpret_cast<unsigned short*>(rlen + 32);    // [NROWS][cap] candidate point indices, ascending
 
     const int q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* pp = patches + (size_t)q * P * 3;
     const float des_r = (float)(*radius);
     const float cx = pp[(size_t)(P - 1) * 3], cy = pp[(size_t)(P - 1) * 3 + 1], cz = pp[(size_t)(P - 1) * 3 + 2];
-
-    for (int i = tid; i < P; i += PF_THREADS) {
-        float x = pp[(size_t)i * 3] - cx, y = pp[(size_t)i * 3 + 1] - cy, z = pp[(size_t)i * 3 + 2] - cz;
-        sp[i] = make_float4(x, y, z, 0.f);
-    }
-    __syncthreads();
-
+    float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
     if (!aligned) {
-        if (wave == 0) {
-            float c00 = 0.f, c01 = 0.f, c02 = 0.f, c11 = 0.f, c12 = 0.f, c22 = 0.f;
-            for (int i = lane; i < P; i += 64) {
-                float4 d = sp[i];
-                c00 = fmaf(d.x, d.x, c00); c01 = fmaf(d.x, d.y, c01); c02 = fmaf(d.x, d.z, c02);
-                c11 = fmaf(d.y, d.y, c11); c12 = fmaf(d.y, d.z, c12); c22 = fmaf(d.z, d.z, c22);
-            }
-            c00 = bx_wave_sum(c00); c01 = bx_wave_sum(c01); c02 = bx_wave_sum(c02);
-            c11 = bx_wave_sum(c11); c12 = bx_wave_sum(c12); c22 = bx_wave_sum(c22);
-            double A[9] = {(double)c00, (double)c01, (double)c02, (double)c01, (double)c11, (double)c12,
-                           (double)c02, (double)c12, (double)c22};
-            double V[9], w[3];
-            bxd_jacobi3(A, V, w);
-            int mi = 0;
-            double mv = fabs(w[0]);
-            if (fabs(w[1]) < mv) { mv = fabs(w[1]); mi = 1; }
-            if (fabs(w[2]) < mv) { mv = fabs(w[2]); mi = 2; }
-            float z0 = (float)(mi == 0 ? V[0] : (mi == 1 ? V[1] : V[2]));
-            float z1 = (float)(mi == 0 ? V[3] : (mi == 1 ? V[4] : V[5]));
-            float z2 = (float)(mi == 0 ? V[6] : (mi == 1 ? V[7] : V[8]));
-            float sdot = ((-z0) * cx + (-z1) * cy) + (-z2) * cz;
-            if (sdot < 0.0f) { z0 = -z0; z1 = -z1; z2 = -z2; }
-            float nz = sqrtf((z0 * z0 + z1 * z1) + z2 * z2);
-            z0 = z0 / nz; z1 = z1 / nz; z2 = z2 / nz;
-            float c0 = z1, c1 = -z0, c2 = 0.0f;
-            float na = sqrtf((z0 * z0 + z1 * z1) + z2 * z2);
-            float nae = na > 1e-8f ? na : 1e-8f;
-            float cosv = z2 / nae;
-            float theta = (float)bxd_acos((double)cosv);
-            double sd, cd;
-            bxd_sincos((double)theta, &sd, &cd);
-            float sn = (float)sd, cs = (float)cd;
-            float nc = sqrtf((c0 * c0 + c1 * c1) + c2 * c2);
-            float nce = nc > 1e-12f ? nc : 1e-12f;
-            c0 = c0 / nce; c1 = c1 / nce; c2 = c2 / nce;
-            float Rx[9] = {0.0f, -c2, c1, c2, 0.0f, -c0, -c1, c0, 0.0f};
-            float Rx2[9];
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    Rx2[i * 3 + j] = fmaf(Rx[i * 3 + 2], Rx[2 * 3 + j], fmaf(Rx[i * 3 + 1], Rx[1 * 3 + j], Rx[i * 3 + 0] * Rx[0 * 3 + j]));
-            float omc = 1.0f - cs;
-            if (lane == 0) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        float I = (i == j) ? 1.0f : 0.0f;
-                        float rr = (I + sn * Rx[i * 3 + j]) + omc * Rx2[i * 3 + j];
-                        sR[j * 3 + i] = rr;  // transpose(-1,-2)
-                    }
-            }
+        for (int i = 0; i < 9; ++i) R[i] = R_out[(size_t)q * 9 + i];
+    } else if (tid < 9) {
+        R_out[(size_t)q * 9 + tid] = (tid % 4 == 0) ? 1.0f : 0.0f;
+    }
+
+    // ---- centre on the keypoint, rotate (delta @ R), normalise by the scale radius
+    for (int i = tid; i < P; i += PF_THREADS) {
+        const float x = pp[(size_t)i * 3] - cx, y = pp[(size_t)i * 3 + 1] - cy, z = pp[(size_t)i * 3 + 2] - cz;
+        float nx = x, ny = y, nzc = z;
+        if (!aligned) {
+            nx = fmaf(z, R[6], fmaf(y, R[3], x * R[0]));
+            ny = fmaf(z, R[7], fmaf(y, R[4], x * R[1]));
+            nzc = fmaf(z, R[8], fmaf(y, R[5], x * R[2]));
         }
-        __syncthreads();
-        float R[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) R[i] = sR[i];
-        for (int i = tid; i < P; i += PF_THREADS) {
-            float4 d = sp[i];
-            float nx = fmaf(d.z, R[6], fmaf(d.y, R[3], d.x * R[0]));
-            float ny = fmaf(d.z, R[7], fmaf(d.y, R[4], d.x * R[1]));
-            float nzc = fmaf(d.z, R[8], fmaf(d.y, R[5], d.x * R[2]));
-            sp[i] = make_float4(nx / des_r, ny / des_r, nzc / des_r, 0.f);
-        }
-        if (tid < 9) R_out[(size_t)q * 9 + tid] = sR[tid];
-    } else {
-        for (int i = tid; i < P; i += PF_THREADS) {
-            float4 d = sp[i];
-            sp[i] = make_float4(d.x / des_r, d.y / des_r, d.z / des_r, 0.f);
-        }
-        if (tid < 9) R_out[(size_t)q * 9 + tid] = (tid % 4 == 0) ? 1.0f : 0.0f;
+        const float px = nx / des_r, py = ny / des_r;
+        sp[i] = make_float4(px, py, nzc / des_r, sqrtf(px * px + py * py));
     }
     __syncthreads();
+    PF_TR(1);
 
     const float vr2 = voxel_r * voxel_r;
-    for (int v0 = 0; v0 < BX_VOX; v0 += PF_THREADS) {
-        const int v = v0 + tid;
-        const bool act = v < BX_VOX;
-        float qx = 0.f, qy = 0.f, qz = 0.f;
-        if (act) { qx = centres[v * 3]; qy = centres[v * 3 + 1]; qz = centres[v * 3 + 2]; }
-        int cnt = act ? 0 : nsample;
-        for (int k0 = 0; k0 < P; k0 += 8) {
-            if (__all(cnt >= nsample)) break;
+
+    // ---- candidate lists per (shell, elevation) row.  The 20 voxel centres of a row lie on the circle {radius R_c,
+    //      height z_c}; a point can only be within voxel_r of one of them if its distance to that CIRCLE is, i.e.
+    //      (R_p - R_c)^2 + (p_z - z_c)^2 < voxel_r^2 (exact inequality; a 1e-4 margin covers fp32 rounding and the
+    //      fp32-rounded centres).  A wave builds the lists of its (up to 3) rows in one sweep over the patch with
+    //      ballot compaction, so a list is in ascending point order and "the first voxel_sample hits in patch order"
+    //      is simply a scan of the row's list.
+    {
+        const float cthr = vr2 * 1.0001f + 1.0e-6f;
+        float Rc[RPW], zc[RPW];
+        int base[RPW];
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                int k = k0 + kk;
-                if (k < P) {
-                    float4 d = sp[k];
-                    float dx = qx - d.x, dy = qy - d.y, dz = qz - d.z;
-                    float dd = (dx * dx + dy * dy) + dz * dz;
-                    if (dd < vr2 && cnt < nsample) {
-                        shit[cnt * BX_VOX + v] = (unsigned short)k;
-                        ++cnt;
-                    }
-                }
+        for (int r = 0; r < RPW; ++r) {
+            const int row = wave + r * PF_WAVES;
+            Rc[r] = row < NROWS ? rowc[row * 2] : 1.0e30f;     // rows beyond the table never pass
+            zc[r] = row < NROWS ? rowc[row * 2 + 1] : 0.f;
+            base[r] = 0;
+        }
+        for (int k0 = 0; k0 < P; k0 += 64) {
+            const int k = k0 + lane;
+            float4 d = make_float4(0.f, 0.f, 1.0e30f, 0.f);
+            if (k < P) d = sp[k];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const float t1 = d.w - Rc[r], t2 = d.z - zc[r];
+                const bool pass = (t1 * t1 + t2 * t2) < cthr;
+                const unsigned long long m = __ballot(pass);
+                const int pos = base[r] + __popcll(m & ((1ULL << lane) - 1ULL));
+                const int row = wave + r * PF_WAVES;
+                if (pass && pos < cap) rlist[(size_t)(row < NROWS ? row : 0) * cap + pos] = (unsigned short)k;
+                base[r] += __popcll(m);
             }
         }
+        // a row with more candidates than its list holds (rare: e.g. the padded points at the keypoint for the inner
+        // shell) is scanned over the whole patch instead: len = -1
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int row = wave + r * PF_WAVES;
+                if (row < NROWS) rlen[row] = base[r] <= cap ? base[r] : -1;
+            }
+        }
+    }
+    __syncthreads();
+    PF_TR(2);
+
+    // ---- voxel query: a wave owns 3 whole rows (60 voxels, lanes 60..63 idle); lanes of one row read the same list
+    //      entries and the same points (LDS broadcast), 8 candidates per step so that the dependent LDS reads of a step
+    //      overlap; each lane tests its own centre and keeps the first `nsample` hits (ascending point order)
+    for (int task = wave; task < NROWS / 3; task += PF_WAVES) {
+        const int rsub = lane / BX_AZI;                   // 0..2, 3 for the idle lanes
+        const bool act = rsub < 3;
+        const int row = task * 3 + (act ? rsub : 0);
+        const int v = row * BX_AZI + (lane - rsub * BX_AZI);
+        float qx = 0.f, qy = 0.f, qz = 0.f;
+        if (act) { qx = centres[v * 3]; qy = centres[v * 3 + 1]; qz = centres[v * 3 + 2]; }
+        const int rl_len = rlen[row];
+        const bool full = rl_len < 0;
+        const int len = act ? (full ? P : rl_len) : 0;
+        const unsigned short* rl = rlist + (size_t)row * cap;
+        int cnt = 0;
+        for (int i0 = 0; ; i0 += 8) {
+            if (__all(cnt >= nsample || i0 >= len)) break;
+            const uint4 kq = *reinterpret_cast<const uint4*>(rl + i0);
+            int ks[8];
+            ks[0] = kq.x & 0xffff; ks[1] = kq.x >> 16; ks[2] = kq.y & 0xffff; ks[3] = kq.y >> 16;
+            ks[4] = kq.z & 0xffff; ks[5] = kq.z >> 16; ks[6] = kq.w & 0xffff; ks[7] = kq.w >> 16;
+            unsigned hm = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int k = full ? i0 + j : ks[j];
+                k = k < P ? k : P - 1;
+                ks[j] = k;
+                const float4 d = sp[k];
+                const float dx = qx - d.x, dy = qy - d.y, dz = qz - d.z;
+                const float dd = (dx * dx + dy * dy) + dz * dz;
+                if (dd < vr2 && i0 + j < len) hm |= 1u << j;
+            }
+            while (hm != 0u && cnt < nsample) {
+                const int j = __ffs((int)hm) - 1;
+                int k = ks[0];
+#pragma unroll
+                for (int u = 1; u < 8; ++u) k = (j == u) ? ks[u] : k;
+                shit[cnt * BX_VOX + v] = (unsigned short)k;
+                ++cnt;
+                hm &= hm - 1u;
+            }
+        }
+        PF_TR(3);
         if (!act) continue;
         const int a = v % BX_AZI;
         const float r00 = rot[a * 4], r01 = rot[a * 4 + 1], r10 = rot[a * 4 + 2], r11 = rot[a * 4 + 3];
@@ -167,6 +253,7 @@ __global__ __launch_bounds__(PF_THREADS) void patch_features_kernel(
         float4* fo = reinterpret_cast<float4*>(feat + (((size_t)q * BX_RAD + s) * BX_EA + pos) * 16);
 #pragma unroll
         for (int u = 0; u < 4; ++u) fo[u] = make_float4(mx[u], mx[4 + u], mx[8 + u], mx[12 + u]);
+        PF_TR(4);
     }
 }
 }  // namespace
@@ -177,10 +264,18 @@ int bxk_patch_features(bx_ctx* c, hipStream_t s, const float* patches, int K, in
     if (K <= 0) return BX_OK;
     const int ns = c->p.voxel_sample;
     if (ns < 1 || ns > MAX_NS || P < 2 || P > 8192) { bx_set_error("bxk_patch_features: voxel_sample=%d P=%d unsupported", ns, P); return BX_ERR_ARG; }
-    size_t lds = (size_t)P * 16 + (size_t)MAX_NS * BX_VOX * 2 + 64;
+    int cap = ((P / 2 + 7) / 8) * 8 + 8;                      // row-list capacity (multiple of 8, one 16-byte read of slack)
+    size_t lds = (size_t)P * 16 + (size_t)ns * BX_VOX * 2 + 128 + (size_t)NROWS * cap * 2 + 16;
+    if (lds > 160 * 1024) { bx_set_error("bxk_patch_features: P=%d needs %zu B of LDS", P, lds); return BX_ERR_ARG; }
+    if (lds > 64 * 1024 && !c->patch_attr_set) {
+        BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(patch_features_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        c->patch_attr_set = 1;
+    }
     const float voxel_r = (float)(c->p.delta / (double)c->p.rad_n);
+    if (!aligned) hipLaunchKernelGGL(patch_axis_kernel, dim3((K + 3) / 4), dim3(256), 0, s, patches, K, P, R_out, c->skip);
     hipLaunchKernelGGL(patch_features_kernel, dim3(K), dim3(PF_THREADS), lds, s, patches, K, P, radius, aligned, c->d_centres,
-                       c->d_rot, ns, voxel_r, c->d_pnt_w, c->d_pnt_b, R_out, feat_out, c->skip);
+                       c->d_rowc, c->d_rot, ns, voxel_r, c->d_pnt_w, c->d_pnt_b, R_out, feat_out, c->skip, cap,
+                       getenv("BX_BALL_DEBUG") ? c->ball_dbg : nullptr);
     BX_LAUNCH_CHECK();
     return BX_OK;
 }

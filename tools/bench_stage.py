@@ -85,6 +85,13 @@ def main():
             _, patches = ctx.ball_group(pp, kp, rad, P, want_idx=False)
             for aligned in (False, True):
                 us = timeit(torch, lambda: ctx.patch_features(patches, rad, aligned), args.iters)
+                if os.environ.get("BX_BALL_DEBUG"):
+                    import ctypes as C
+                    buf = (C.c_int64 * 480)()
+                    ctx.lib.bx_debug_read(ctx.handle, buf, 480)
+                    a = np.array(buf[:]).reshape(60, 8)
+                    print("patch phases (median cycles, wave 0): normalised %d rowlists %d query %d conv+store %d"
+                          % tuple(np.median(a[:, 1:5], 0).astype(int)))
                 out.append(dict(stage="patch_features", K=K, P=P, radius=float(rr[si]), aligned=aligned, us=round(us, 2)))
     if args.what in ("conv", "all"):
         _, patches = ctx.ball_group(pp, kp, radii[0:1].contiguous(), P, want_idx=False)
