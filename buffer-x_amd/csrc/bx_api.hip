@@ -137,34 +137,45 @@ void voxel_tables(std::vector<float>& cen, std::vector<float>& rot, std::vector<
     }
 }
 
-std::vector<int32_t> cyl_taps()
+// LDS staging geometry of the convolution kernel (k_conv.hip): cylindrical maps (reference pad_image / pad_image_3d,
+// utils/common.py:265-310: circular in azimuth, zero in elevation) are staged with a halo so that a tap is a constant
+// row offset; the un-padded ("valid") CostNet convolutions (models/patchnet.py:192-210) need no halo.
+struct ConvGeo { std::vector<int32_t> lrow, lrow2, obase, toff; int p_lds; };
+
+ConvGeo cyl_geo()
 {
-    std::vector<int32_t> t((size_t)9 * BX_EA, -1);
+    ConvGeo g;
+    const int WP = BX_AZI + 2;
+    g.p_lds = (BX_ELE + 2) * WP;
+    g.lrow.resize(BX_EA); g.lrow2.resize(BX_EA); g.obase.resize(BX_EA); g.toff.resize(9);
+    for (int h = 0; h < BX_ELE; ++h)
+        for (int w = 0; w < BX_AZI; ++w) {
+            const int p = h * BX_AZI + w;
+            g.lrow[p] = (h + 1) * WP + (w + 1);
+            g.lrow2[p] = w == 0 ? (h + 1) * WP + (BX_AZI + 1) : (w == BX_AZI - 1 ? (h + 1) * WP : -1);
+            g.obase[p] = h * WP + w;
+        }
     for (int kh = 0; kh < 3; ++kh)
-        for (int kw = 0; kw < 3; ++kw)
-            for (int h = 0; h < BX_ELE; ++h) {
-                int hh = h + kh - 1;
-                if (hh < 0 || hh >= BX_ELE) continue;
-                for (int w = 0; w < BX_AZI; ++w)
-                    t[(size_t)(kh * 3 + kw) * BX_EA + h * BX_AZI + w] = hh * BX_AZI + (w + kw - 1 + BX_AZI) % BX_AZI;
-            }
-    return t;
+        for (int kw = 0; kw < 3; ++kw) g.toff[kh * 3 + kw] = kh * WP + kw;
+    return g;
 }
 
-std::vector<int32_t> valid_taps(const int d[3], const int k[3], int o[3])
+ConvGeo valid_geo(const int d[3], const int k[3], int o[3])
 {
     for (int i = 0; i < 3; ++i) o[i] = d[i] - k[i] + 1;
-    std::vector<int32_t> t((size_t)k[0] * k[1] * k[2] * o[0] * o[1] * o[2]);
-    const int po = o[0] * o[1] * o[2];
+    ConvGeo g;
+    const int pin = d[0] * d[1] * d[2];
+    g.p_lds = pin;
+    g.lrow.resize(pin); g.lrow2.assign(pin, -1);
+    for (int p = 0; p < pin; ++p) g.lrow[p] = p;
+    g.obase.resize((size_t)o[0] * o[1] * o[2]);
+    for (int z = 0; z < o[0]; ++z)
+        for (int y = 0; y < o[1]; ++y)
+            for (int x = 0; x < o[2]; ++x) g.obase[(size_t)(z * o[1] + y) * o[2] + x] = (z * d[1] + y) * d[2] + x;
     for (int a = 0; a < k[0]; ++a)
         for (int b = 0; b < k[1]; ++b)
-            for (int c = 0; c < k[2]; ++c)
-                for (int z = 0; z < o[0]; ++z)
-                    for (int y = 0; y < o[1]; ++y)
-                        for (int x = 0; x < o[2]; ++x)
-                            t[(size_t)((a * k[1] + b) * k[2] + c) * po + (z * o[1] + y) * o[2] + x] =
-                                ((z + a) * d[1] + (y + b)) * d[2] + (x + c);
-    return t;
+            for (int c = 0; c < k[2]; ++c) g.toff.push_back((a * d[1] + b) * d[2] + c);
+    return g;
 }
 
 template <typename T>
@@ -324,8 +335,8 @@ int bx_destroy(bx_ctx* c)
     (void)hipFree(c->arena);
     (void)hipFree(c->d_centres); (void)hipFree(c->d_rot); (void)hipFree(c->d_rowc); (void)hipFree(c->d_rad_thr);
     (void)hipFree(c->d_pnt_w); (void)hipFree(c->d_pnt_b); (void)hipFree(c->d_pool_w1); (void)hipFree(c->d_pool_b1); (void)hipFree(c->d_pool_w2); (void)hipFree(c->d_pool_b2);
-    for (int i = 0; i < BX_NDESC; ++i) { (void)hipFree(c->desc[i].W); (void)hipFree(c->desc[i].b); (void)hipFree(c->desc[i].tap); }
-    for (int i = 0; i < BX_NPOSE; ++i) { (void)hipFree(c->pose[i].W); (void)hipFree(c->pose[i].b); (void)hipFree(c->pose[i].tap); }
+    for (int i = 0; i < BX_NDESC; ++i) { (void)hipFree(c->desc[i].W); (void)hipFree(c->desc[i].b); (void)hipFree(c->desc[i].lrow); (void)hipFree(c->desc[i].lrow2); (void)hipFree(c->desc[i].obase); (void)hipFree(c->desc[i].toff); }
+    for (int i = 0; i < BX_NPOSE; ++i) { (void)hipFree(c->pose[i].W); (void)hipFree(c->pose[i].b); (void)hipFree(c->pose[i].lrow); (void)hipFree(c->pose[i].lrow2); (void)hipFree(c->pose[i].obase); (void)hipFree(c->pose[i].toff); }
     delete c;
     return BX_OK;
 }
@@ -376,13 +387,21 @@ int bx_load_weights(bx_ctx* c, const bx_weights* w)
     if ((rc = upload(&c->d_pool_b2, w->pool_b2, 1)) != BX_OK) return rc;
     // Desc: Cylindrical_Net (models/patchnet.py:72-84)
     static const int dc[BX_NDESC][2] = {{3, 64}, {4, 64}, {4, 128}, {8, 128}, {8, 64}, {4, 64}, {4, 32}, {2, 32}};
-    std::vector<int32_t> ct = cyl_taps();
+    const ConvGeo cg = cyl_geo();
+    auto upload_geo = [&](ConvLayerDev& L, const ConvGeo& g) -> int {
+        int r;
+        L.p_lds = g.p_lds;
+        if ((r = upload(&L.lrow, g.lrow.data(), g.lrow.size())) != BX_OK) return r;
+        if ((r = upload(&L.lrow2, g.lrow2.data(), g.lrow2.size())) != BX_OK) return r;
+        if ((r = upload(&L.obase, g.obase.data(), g.obase.size())) != BX_OK) return r;
+        return upload(&L.toff, g.toff.data(), g.toff.size());
+    };
     for (int l = 0; l < BX_NDESC; ++l) {
         ConvLayerDev& L = c->desc[l];
         L.nchunk = dc[l][0]; L.ntaps = 9; L.p_in = BX_EA; L.p_out = BX_EA; L.cout = dc[l][1]; L.relu = l < BX_NDESC - 1;
         if ((rc = upload(&L.W, w->desc_w[l], (size_t)L.nchunk * 9 * 16 * L.cout)) != BX_OK) return rc;
         if ((rc = upload(&L.b, w->desc_b[l], (size_t)L.cout)) != BX_OK) return rc;
-        if ((rc = upload(&L.tap, ct.data(), ct.size())) != BX_OK) return rc;
+        if ((rc = upload_geo(L, cg)) != BX_OK) return rc;
     }
     // Pose: CostNet (models/patchnet.py:196-210) on the [azi, ele-2, azi] cost volume
     static const int pc[BX_NPOSE][2] = {{2, 32}, {2, 64}, {4, 64}, {4, 128}, {8, 128}, {8, 64}, {4, 64}, {4, 32}, {2, 32}, {2, 20}};
@@ -391,13 +410,13 @@ int bx_load_weights(bx_ctx* c, const bx_weights* w)
         int k[3] = {3, l < 2 ? 3 : 1, 3};
         if (l == BX_NPOSE - 1) { k[0] = 2; k[1] = 1; k[2] = 2; }
         int o[3];
-        std::vector<int32_t> vt = valid_taps(dims, k, o);
+        const ConvGeo vg = valid_geo(dims, k, o);
         ConvLayerDev& L = c->pose[l];
         L.nchunk = pc[l][0]; L.ntaps = k[0] * k[1] * k[2]; L.p_in = dims[0] * dims[1] * dims[2]; L.p_out = o[0] * o[1] * o[2];
         L.cout = pc[l][1]; L.relu = l < BX_NPOSE - 1;
         if ((rc = upload(&L.W, w->pose_w[l], (size_t)L.nchunk * L.ntaps * 16 * L.cout)) != BX_OK) return rc;
         if ((rc = upload(&L.b, w->pose_b[l], (size_t)L.cout)) != BX_OK) return rc;
-        if ((rc = upload(&L.tap, vt.data(), vt.size())) != BX_OK) return rc;
+        if ((rc = upload_geo(L, vg)) != BX_OK) return rc;
         for (int i = 0; i < 3; ++i) dims[i] = o[i];
     }
     c->weights_loaded = true;

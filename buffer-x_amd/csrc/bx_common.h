@@ -29,8 +29,11 @@ constexpr int BX_NDESC = 8, BX_NPOSE = 10;
 struct ConvLayerDev {
     float* W;        // [nchunk][ntaps][16][cout]
     float* b;        // [cout]
-    int32_t* tap;    // [ntaps][p_out]
-    int nchunk, ntaps, p_in, p_out, cout, relu;
+    int32_t* lrow;   // [p_in]  LDS row of an input position inside a unit's p_lds-row slab
+    int32_t* lrow2;  // [p_in]  second copy (azimuth wrap halo) or -1
+    int32_t* obase;  // [p_out] LDS row of the window origin of an output position
+    int32_t* toff;   // [ntaps] row offset of a tap
+    int nchunk, ntaps, p_in, p_lds, p_out, cout, relu;
 };
 
 // device-side per-pair state written/read by the pipeline kernels (no host round trips)

@@ -11,260 +11,258 @@
 // fmaf chain, so the result equals the oracle's  acc = bias; for chunk/tap/c: acc = fmaf(x, w, acc)
 // bit for bit -- BatchNorm folded, ReLU fused into the epilogue.
 //
-// Workgroup = 8 waves, G units: the G*P_IN x 16 input slab of one chunk is staged in LDS (80-byte rows ->
-// conflict-light b128 reads; double-buffered against the next chunk's global loads), padding / geometry is
-// a per-workgroup row-offset table built from the layer's tap table (zero padding -> a shared zero row),
-// wave (wm, wn) owns output tiles {wm + t*WM} x 16 channels with fp32 accumulators in VGPRs, weights
-// stream from L2 as B fragments (one dword per lane per MFMA, reused across the wave's tiles).
+// Workgroup = 8 waves, G units: the input slab of one chunk is staged in LDS (80-byte rows, double-buffered
+// against the next chunk's global loads) WITH its halo, so padding / wrap-around are plain rows and a tap is a
+// constant row offset; wave (wm, wn) owns output tiles {wm + t*WM} x 16 channels with fp32 accumulators in VGPRs,
+// weights stream from L2 as B fragments (one dword per lane per MFMA, reused across the wave's tiles).
 #include "bx_common.h"
 #include <cstdlib>
 
 namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int CT = 512;    // threads
 constexpr int ROWF = 20;   // floats per LDS row (16 + 4 pad)
 
-template <int NCHUNK, int NTAPS, int P_IN, int P_OUT, int COUT, int G, bool RELU, bool DB>
+// Geometry is table-driven (ConvLayerDev, built on the host per layer) so that the MFMA loop carries NO address
+// arithmetic beyond one add per tile:
+//   lrow [P_IN]   LDS row (inside one unit's P_LDS-row slab) that receives input position p; lrow2 [P_IN] a second
+//                 copy or -1.  Cylindrical maps are staged with a halo -- (7+2) x (20+2) rows: the azimuth wrap-around
+//                 columns are copies, the elevation padding rows are zeros -- so that EVERY tap of EVERY output
+//                 position is "window origin + constant": no per-tap lookup, no padding special cases.
+//   obase[P_OUT]  LDS row of the window origin of output position pos;   toff [NTAPS] row offset of a tap.
+// Measured on this chip (tools/ubench/mfma_mix.hip): every non-MFMA instruction in the loop costs matrix-pipe time,
+// and the 4 MFMAs of a tile are fastest as a back-to-back dependent chain (153 TF pure, 124 TF when the compiler
+// interleaves accumulators); hence one ds_read_b128 + one v_add per tile and a pinned tile-major order.
+template <int NCHUNK, int NTAPS, int P_IN, int P_LDS, int P_OUT, int COUT, int G, bool RELU, int NW, int NPW>
 struct ConvCfg {
+    static constexpr int CT = NW * 64;    // threads
     static constexpr int M = G * P_OUT;
     static constexpr int MT = (M + 15) / 16;
     static constexpr int NT = (COUT + 15) / 16;
-    static constexpr int WN = NT;
-    static constexpr int WM = 8 / WN;
+    static constexpr int WN = NT / NPW;       // NPW column tiles per wave: one A read feeds 4*NPW MFMAs
+    static constexpr int WM = NW / WN;
     static constexpr int TPW = (MT + WM - 1) / WM;
-    static constexpr int ROWS = G * P_IN;
-    static constexpr int BUF_FLOATS = (ROWS + 1) * ROWF;
-    static constexpr int NBUF = DB ? 2 : 1;
-    static constexpr int NLD = (ROWS * 4 + CT - 1) / CT;
-    static constexpr size_t LDS_BYTES = (size_t)NBUF * BUF_FLOATS * 4 + (size_t)NTAPS * MT * 16 * 2;
-    // register budget: two co-resident workgroups (4 waves/SIMD, <= 128 VGPRs) whenever the accumulator tile allows it
-    static constexpr int MINW = (LDS_BYTES <= 80 * 1024 && (TPW <= 10 || P_IN == 140)) ? 4 : 2;
-    // fat accumulator tiles: no one-tap-ahead row-offset registers / pinned A pairs (they would cost the second workgroup)
-    static constexpr bool LEAN = TPW > 10;
-    static_assert(NT == 2 || NT == 4 || NT == 8, "COUT must give 2/4/8 column tiles");
-    static_assert(ROWS + 1 < 65536, "row table is u16");
+    static constexpr int ROWS = G * P_LDS;
+    static constexpr int BUF_FLOATS = ROWS * ROWF;
+    static constexpr int NLD = (G * P_IN * 4 + CT - 1) / CT;
+    static constexpr size_t LDS_BYTES = (size_t)2 * BUF_FLOATS * 4;
+    // taps whose B fragments are all requested before the next slab's loads go out (see the tail of the tap loop)
+    static constexpr int KT = NTAPS - 1 < 2 ? NTAPS - 1 : (TPW > 10 ? 1 : 2);
+    // register budget: two co-resident workgroups (4 waves/SIMD, <= 128 VGPRs) when LDS allows two
+    // register budget: as many co-resident workgroups as the LDS allows (they desynchronise and cover each other's
+    // prologue / barrier / epilogue phases), capped where the accumulator tile would spill
+    static constexpr int WG_LDS = (int)(160 * 1024 / LDS_BYTES);
+    static constexpr int WPS_WANT = WG_LDS * NW / 4;                       // waves per SIMD the LDS would admit
+    static constexpr int WPS_CAP = TPW * NPW <= 5 ? 6 : (TPW * NPW <= 10 ? (NW == 4 ? 5 : 4) : 2);
+    static constexpr int MINW = WPS_WANT < WPS_CAP ? (WPS_WANT < 1 ? 1 : WPS_WANT) : WPS_CAP;
+    static_assert(NT % NPW == 0 && WN <= NW && NW % WN == 0, "waves must tile the output channels");
+    static_assert(LDS_BYTES <= 160 * 1024, "slab double buffer exceeds the LDS");
+    static_assert(NTAPS <= 64, "tap offsets live in one lane each");
 };
 
-// Persistent workgroups: workgroup b walks the unit groups b, b + gridDim.x, ... and treats (group, chunk) as ONE flat
-// sequence of input slabs: while slab s is on the matrix cores, slab s+1 (the next chunk, or chunk 0 of the NEXT group)
-// is already in flight from HBM, so neither the per-group prologue (row table, first load) nor the epilogue stores
-// leave the MFMA pipe idle.  The row table depends only on the layer geometry and is built once per workgroup.
-template <int NCHUNK, int NTAPS, int P_IN, int P_OUT, int COUT, int G, bool RELU, bool DB>
-__global__ __launch_bounds__(CT, (ConvCfg<NCHUNK, NTAPS, P_IN, P_OUT, COUT, G, RELU, DB>::MINW)) void conv_kernel(const float* __restrict__ in, const int32_t* __restrict__ units_dev,
-                                                  int max_units, const float* __restrict__ W, const float* __restrict__ bias,
-                                                  const int32_t* __restrict__ tap, float* __restrict__ out,
-                                                  const int32_t* __restrict__ skip)
+template <int NCHUNK, int NTAPS, int P_IN, int P_LDS, int P_OUT, int COUT, int G, bool RELU, int NW, int NPW>
+__global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT, COUT, G, RELU, NW, NPW>::MINW)) void conv_kernel(
+    const float* __restrict__ in, const int32_t* __restrict__ units_dev, int max_units, const float* __restrict__ W,
+    const float* __restrict__ bias, const int32_t* __restrict__ lrow, const int32_t* __restrict__ lrow2,
+    const int32_t* __restrict__ obase, const int32_t* __restrict__ toff, float* __restrict__ out,
+    const int32_t* __restrict__ skip, long long* __restrict__ dbg)
 {
     if (skip && *skip) return;
-    using C = ConvCfg<NCHUNK, NTAPS, P_IN, P_OUT, COUT, G, RELU, DB>;
+    using C = ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT, COUT, G, RELU, NW, NPW>;
+    constexpr int CT = C::CT;
+    // optional cycle stamps (BX_BALL_DEBUG): 16 workgroups x {t0, prologue, [taps done, barrier passed] per chunk, end}
+    long long t0_ = 0;
+    const bool tr_ = dbg != nullptr && (blockIdx.x % 151) == 0 && blockIdx.x / 151 < 16 && threadIdx.x == 0;
+    long long* td_ = dbg + (blockIdx.x / 151) * 32;
+    if (tr_) { t0_ = __builtin_readcyclecounter(); td_[0] = t0_; }
+#define CV_TR(k) do { if (tr_) td_[k] = __builtin_readcyclecounter() - t0_; } while (0)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* buf = reinterpret_cast<float*>(smem);
-    unsigned short* roff = reinterpret_cast<unsigned short*>(buf + (size_t)C::NBUF * C::BUF_FLOATS);
 
     int units = max_units;
     if (units_dev) { int u = *units_dev; units = u < max_units ? u : max_units; }
-    const int ngroups = (units + G - 1) / G;
-    if ((int)blockIdx.x >= ngroups) return;
-    const int my_groups = (ngroups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int nslabs = my_groups * NCHUNK;
+    const int u0 = blockIdx.x * G;
+    if (u0 >= units) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave % C::WN, wm = wave / C::WN;
     const int li = lane & 15, kk = lane >> 4;
 
-    // ---- row-offset table (geometry + padding; rows of units beyond the tail group are loaded as zeros), zero rows
-    for (int idx = tid; idx < NTAPS * C::MT * 16; idx += CT) {
-        int tp = idx / (C::MT * 16), m = idx - tp * (C::MT * 16);
-        int r = C::ROWS;
-        if (m < C::M) {
-            int g = m / P_OUT, pos = m - g * P_OUT;
-            int ip = tap[tp * P_OUT + pos];
-            if (ip >= 0) r = g * P_IN + ip;
-        }
-        roff[idx] = (unsigned short)r;
-    }
-    if (tid < ROWF * C::NBUF) {
-        int b = tid / ROWF;
-        buf[(size_t)b * C::BUF_FLOATS + (size_t)C::ROWS * ROWF + (tid - b * ROWF)] = 0.0f;
-    }
+    // ---- both slab buffers start as zeros (the halo rows stay zero for the whole kernel)
+    for (int i = tid; i < 2 * C::BUF_FLOATS / 4; i += CT) reinterpret_cast<float4*>(buf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // ---- staging helpers: slab s = (group blockIdx.x + (s / NCHUNK) * gridDim.x, chunk s % NCHUNK)
+    // ---- staging geometry of this thread's float4 pieces (constant over the chunks)
     const float4* in4 = reinterpret_cast<const float4*>(in);
     float4 st[C::NLD];
-    auto gload = [&](int s_) {
-        const int gi = s_ / NCHUNK, cc = s_ - gi * NCHUNK;
-        const int u0 = ((int)blockIdx.x + gi * (int)gridDim.x) * G;
+    // (the piece geometry is recomputed per chunk from an opaque copy of tid: keeping 3*NLD hoisted address registers
+    //  alive across the MFMA loop costs the second co-resident workgroup on the 18-tile configurations)
+    auto piece = [&](int tq, int q, int& src, int& dst1, int& dst2) {
+        const int f = tq + q * CT;
+        const int row = f >> 2, part = f & 3;
+        const int g = row / P_IN, p = row - g * P_IN;
+        src = -1; dst1 = -1; dst2 = -1;
+        if (row < G * P_IN) {
+            dst1 = (g * P_LDS + lrow[p]) * ROWF + part * 4;
+            const int r2 = lrow2[p];
+            if (r2 >= 0) dst2 = (g * P_LDS + r2) * ROWF + part * 4;
+            if (u0 + g < units) src = ((u0 + g) * NCHUNK * P_IN + p) * 4 + part;   // float4 index of chunk 0 (< 2^31 at these sizes)
+        }
+    };
+    auto gload = [&](int cc) {
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
 #pragma unroll
         for (int q = 0; q < C::NLD; ++q) {
-            int f = tid + q * CT;
-            int row = f >> 2, part = f & 3;
-            int g = row / P_IN, p = row - g * P_IN;
-            if (row < C::ROWS && u0 + g < units)
-                st[q] = in4[(((size_t)(u0 + g) * NCHUNK + cc) * P_IN + p) * 4 + part];
-            else
-                st[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            int src, d1, d2;
+            piece(tq, q, src, d1, d2);
+            st[q] = src >= 0 ? in4[(size_t)src + (size_t)cc * P_IN * 4] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto lwrite = [&](int b) {
         float* d = buf + (size_t)b * C::BUF_FLOATS;
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
 #pragma unroll
         for (int q = 0; q < C::NLD; ++q) {
-            int f = tid + q * CT;
-            int row = f >> 2, part = f & 3;
-            if (row < C::ROWS) *reinterpret_cast<float4*>(d + (size_t)row * ROWF + part * 4) = st[q];
+            int src, d1, d2;
+            piece(tq, q, src, d1, d2);
+            if (d1 >= 0) *reinterpret_cast<float4*>(d + d1) = st[q];
+            if (d2 >= 0) *reinterpret_cast<float4*>(d + d2) = st[q];
         }
     };
 
+    // ---- A-operand byte offset of every tile row owned by this lane (window origin), tap offsets one per lane
+    int abase[C::TPW];
+#pragma unroll
+    for (int t = 0; t < C::TPW; ++t) {
+        const int m = (wm + t * C::WM) * 16 + li;
+        int r = 0;                                       // rows beyond M compute garbage that is never stored
+        if (m < C::M) { const int g = m / P_OUT, pos = m - g * P_OUT; r = g * P_LDS + obase[pos]; }
+        abase[t] = (r * ROWF + kk * 4) * 4;
+    }
+    const int toffv = lane < NTAPS ? toff[lane] * (ROWF * 4) : 0;
+
     gload(0);
+    __syncthreads();          // zero fill complete before the first slab lands on top of it
     lwrite(0);
     __syncthreads();
 
-    const int n0 = wn * 16;
-    const bool colok = (n0 + li) < COUT;
-    const float bv = colok ? bias[n0 + li] : 0.0f;
-    f32x4 acc[C::TPW];
-
-    // B fragments (weights, L2-resident) and the A row offsets are fetched ONE TAP AHEAD of the MFMAs that consume
-    // them, so neither the ~500-cycle L2 round trip nor the dependent LDS table read sits in front of the matrix pipe.
-    // A wave whose last tile does not exist (mt >= MT) runs it on the zero row: uniform schedule, no exec-mask branches.
-    const float* wbase = W + (size_t)kk * COUT + n0 + li;
-    auto loadB = [&](int ct, float (&b)[4]) {
-        const float* wp = wbase + (size_t)ct * 16 * COUT;
-        b[0] = colok ? wp[0] : 0.f;
-        b[1] = colok ? wp[4 * COUT] : 0.f;
-        b[2] = colok ? wp[8 * COUT] : 0.f;
-        b[3] = colok ? wp[12 * COUT] : 0.f;
-    };
-    auto loadR = [&](int tp, int (&r)[C::TPW]) {
-        const unsigned short* ro = roff + (size_t)tp * C::MT * 16 + li;
+    // ---- accumulators start at the (BN-folded) bias; a wave owns NPW column tiles of 16 channels
+    const int n0 = wn * NPW * 16;
+    bool colok[NPW];
+    f32x4 acc[C::TPW][NPW];
 #pragma unroll
-        for (int t = 0; t < C::TPW; ++t) {
-            const int mt = wm + t * C::WM;
-            r[t] = mt < C::MT ? (int)ro[mt * 16] : C::ROWS;
+    for (int j = 0; j < NPW; ++j) {
+        colok[j] = (n0 + j * 16 + li) < COUT;
+        const float bv = colok[j] ? bias[n0 + j * 16 + li] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < C::TPW; ++t) acc[t][j] = (f32x4){bv, bv, bv, bv};
+    }
+
+    const float* wbase = W + (size_t)kk * COUT + n0 + li;
+    auto loadB = [&](int ct, float (&b)[NPW][4]) {
+        const float* wp = wbase + (size_t)ct * 16 * COUT;
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) {
+            b[j][0] = colok[j] ? wp[j * 16] : 0.f;
+            b[j][1] = colok[j] ? wp[j * 16 + 4 * COUT] : 0.f;
+            b[j][2] = colok[j] ? wp[j * 16 + 8 * COUT] : 0.f;
+            b[j][3] = colok[j] ? wp[j * 16 + 12 * COUT] : 0.f;
         }
     };
-    float bc[4], bn[4];
-    int rc[C::TPW], rn[C::TPW];
+    float bc[NPW][4], bn[NPW][4];
     loadB(0, bc);
-    if constexpr (!C::LEAN) loadR(0, rc);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bn[i] = 0.f;
+    for (int j = 0; j < NPW; ++j)
 #pragma unroll
-    for (int t = 0; t < C::TPW; ++t) rn[t] = C::ROWS;
+        for (int i = 0; i < 4; ++i) bn[j][i] = 0.f;
     // drain the prologue loads here: otherwise the waitcnt pass sees them pending on the loop's entry edge and
     // waits for the NEWEST loads (the counters are in-order) in front of every tap's first MFMAs
     __builtin_amdgcn_s_waitcnt(0);
+    CV_TR(1);
 
-    const int slot = 4 * (li & 3) + (li >> 2);
-    int cc = 0, gi = 0;
-    for (int s_ = 0; s_ < nslabs; ++s_) {
-        const int cur = DB ? (s_ & 1) : 0;
-        if (cc == 0) {
-#pragma unroll
-            for (int t = 0; t < C::TPW; ++t) acc[t] = (f32x4){bv, bv, bv, bv};
-        }
-        if (DB && s_ + 1 < nslabs) gload(s_ + 1);
-        const float* lb = buf + (size_t)cur * C::BUF_FLOATS + kk * 4;
-#pragma unroll 1
-        for (int tp = 0; tp < NTAPS; ++tp) {
-            {
-                int ctn = cc * NTAPS + tp + 1;
-                if (ctn == NCHUNK * NTAPS) ctn = 0;      // first tap of the next group's chunk 0 (harmless after the last slab)
-                loadB(ctn, bn);
-                if constexpr (!C::LEAN) loadR(tp + 1 < NTAPS ? tp + 1 : 0, rn);
-            }
-#ifdef BX_EXP_NOLDS
-#define BX_A(r) (f32x4){(float)(r), bc[1], bc[2], bc[3]}
-#else
-#define BX_A(r) (*reinterpret_cast<const f32x4*>(lb + (size_t)(r) * ROWF))
-#endif
-            if constexpr (C::LEAN) {
-                const unsigned short* ro = roff + (size_t)tp * C::MT * 16 + li;
-#pragma unroll
-                for (int t = 0; t < C::TPW; ++t) {
-                    const int mt = wm + t * C::WM;
-                    if (mt < C::MT) {
-                        f32x4 a = BX_A((int)ro[mt * 16]);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bc[0], acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bc[1], acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bc[2], acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bc[3], acc[t], 0, 0, 0);
-                    }
-                }
-            } else {
-            // two tiles in flight, the next pair's A operands requested before this pair's MFMAs issue
-                f32x4 a0 = BX_A(rc[0]);
-                f32x4 a1 = C::TPW > 1 ? BX_A(rc[C::TPW > 1 ? 1 : 0]) : a0;
-#pragma unroll
-                for (int t = 0; t + 1 < C::TPW; t += 2) {
-                    f32x4 n0v = a0, n1v = a1;
-                    if (t + 2 < C::TPW) n0v = BX_A(rc[t + 2 < C::TPW ? t + 2 : 0]);
-                    if (t + 3 < C::TPW) n1v = BX_A(rc[t + 3 < C::TPW ? t + 3 : 0]);
-                    // (pinning this order with sched_barrier measured 10 % SLOWER than the compiler's own schedule)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bc[0], acc[t], 0, 0, 0);
-                    acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bc[0], acc[t + 1], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bc[1], acc[t], 0, 0, 0);
-                    acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bc[1], acc[t + 1], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bc[2], acc[t], 0, 0, 0);
-                    acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bc[2], acc[t + 1], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bc[3], acc[t], 0, 0, 0);
-                    acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bc[3], acc[t + 1], 0, 0, 0);
-                    a0 = n0v; a1 = n1v;
-                }
-                if (C::TPW & 1) {
-                    constexpr int t = C::TPW - 1;
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bc[0], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bc[1], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bc[2], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bc[3], acc[t], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bc[i] = bn[i];
-            if constexpr (!C::LEAN) {
-#pragma unroll
-                for (int t = 0; t < C::TPW; ++t) rc[t] = rn[t];
-            }
-        }
-        if (cc == NCHUNK - 1) {
-            // ---- epilogue of this group: ReLU, store in chunk-slot order (fire-and-forget; the next slab's MFMAs follow)
-            const int u0 = ((int)blockIdx.x + gi * (int)gridDim.x) * G;
-            int mrow0 = kk * 4;
-            asm volatile("" : "+v"(mrow0));   // keeps the 4*TPW store addresses out of the loop-invariant hoisting (VGPR budget)
+    for (int cc = 0; cc < NCHUNK; ++cc) {
+        const char* lb = reinterpret_cast<const char*>(buf + (size_t)(cc & 1) * C::BUF_FLOATS);
+        // one tap: per tile ONE address add + ONE ds_read_b128 (issued two tiles ahead) + 4 back-to-back MFMAs
+        auto do_tap = [&](int tp, const float (&b_)[NPW][4]) {
+            const int tb = __builtin_amdgcn_readlane(toffv, tp);
+            const char* lt = lb + tb;
+            f32x4 a[C::TPW];
+            a[0] = *reinterpret_cast<const f32x4*>(lt + abase[0]);
+            if (C::TPW > 1) a[C::TPW > 1 ? 1 : 0] = *reinterpret_cast<const f32x4*>(lt + abase[C::TPW > 1 ? 1 : 0]);
 #pragma unroll
             for (int t = 0; t < C::TPW; ++t) {
-                const int mt = wm + t * C::WM;
-                if (mt >= C::MT) continue;
+                if (t + 2 < C::TPW) a[t + 2 < C::TPW ? t + 2 : 0] = *reinterpret_cast<const f32x4*>(lt + abase[t + 2 < C::TPW ? t + 2 : 0]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int m = mt * 16 + mrow0 + r;
-                    if (m < C::M) {
-                        int g = m / P_OUT, pos = m - g * P_OUT;
-                        if (u0 + g < units) {
-                            float v = acc[t][r];
-                            if (RELU) v = v > 0.0f ? v : 0.0f;
-                            out[(((size_t)(u0 + g) * C::NT + wn) * P_OUT + pos) * 16 + slot] = v;
-                        }
+                for (int j = 0; j < NPW; ++j) {
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, b_[j][0], acc[t][j], 0, 0, 0);
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, b_[j][1], acc[t][j], 0, 0, 0);
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, b_[j][2], acc[t][j], 0, 0, 0);
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, b_[j][3], acc[t][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // head taps [0, T0): the B fragment of the next tap is fetched while the current one is on the matrix cores
+        constexpr int KT = C::KT, T0 = NTAPS - 1 - KT;
+#pragma unroll 1
+        for (int tp = 0; tp < T0; ++tp) {
+            loadB(cc * NTAPS + tp + 1, bn);
+            do_tap(tp, bc);
+#pragma unroll
+            for (int j = 0; j < NPW; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bc[j][i] = bn[j][i];
+        }
+        // tail taps [T0, NTAPS): vmcnt retires IN ORDER, so a B fetch issued after the slab load would wait for the
+        // slab's HBM round trip.  Every remaining B fragment of this chunk AND the first one of the next chunk are
+        // requested first, THEN the next slab's loads go out; nothing waits on them until the LDS hand-off below.
+        {
+            float bt[KT + 1][NPW][4];
+#pragma unroll
+            for (int i = 0; i <= KT; ++i) {
+                int ctn = cc * NTAPS + T0 + 1 + i;
+                if (ctn >= NCHUNK * NTAPS) ctn -= NCHUNK * NTAPS;   // harmless extra fetch after the last chunk
+                loadB(ctn, bt[i]);
+            }
+            if (cc + 1 < NCHUNK) gload(cc + 1);
+            do_tap(T0, bc);
+#pragma unroll
+            for (int i = 0; i < KT; ++i) do_tap(T0 + 1 + i, bt[i]);
+#pragma unroll
+            for (int j = 0; j < NPW; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bc[j][i] = bt[KT][j][i];
+        }
+        CV_TR(2 + 2 * cc);
+        if (cc + 1 < NCHUNK) lwrite((cc + 1) & 1);
+        __syncthreads();
+        CV_TR(3 + 2 * cc);
+    }
+
+    // ---- epilogue: ReLU, store in chunk-slot order
+    const int slot = 4 * (li & 3) + (li >> 2);
+#pragma unroll
+    for (int t = 0; t < C::TPW; ++t) {
+        const int mt = wm + t * C::WM;
+        if (mt >= C::MT) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int m = mt * 16 + kk * 4 + r;
+            if (m < C::M) {
+                int g = m / P_OUT, pos = m - g * P_OUT;
+                if (u0 + g < units) {
+#pragma unroll
+                    for (int j = 0; j < NPW; ++j) {
+                        float v = acc[t][j][r];
+                        if (RELU) v = v > 0.0f ? v : 0.0f;
+                        out[(((size_t)(u0 + g) * C::NT + wn * NPW + j) * P_OUT + pos) * 16 + slot] = v;
                     }
                 }
             }
         }
-#ifdef BX_EXP_NOSYNC
-        if (DB) {
-            if (s_ + 1 < nslabs && s_ < 0) lwrite(cur ^ 1);
-        } else
-#endif
-        if (DB) {
-            if (s_ + 1 < nslabs) lwrite(cur ^ 1);
-            __syncthreads();
-        } else if (s_ + 1 < nslabs) {
-            __syncthreads();
-            gload(s_ + 1);
-            lwrite(0);
-            __syncthreads();
-        }
-        if (++cc == NCHUNK) { cc = 0; ++gi; }
     }
+    CV_TR(2 + 2 * NCHUNK);
 }
 
 // ---------------------------------------------------------------- CostNet layer 0 on the implicit cost volume
@@ -272,6 +270,7 @@ __global__ __launch_bounds__(CT, (ConvCfg<NCHUNK, NTAPS, P_IN, P_OUT, COUT, G, R
 constexpr int CV_D = BX_AZI, CV_H = BX_ELE - 2, CV_W = BX_AZI;       // 20 x 5 x 20
 constexpr int CV_DO = CV_D - 2, CV_HO = CV_H - 2, CV_WO = CV_W - 2;  // 18 x 3 x 18
 constexpr int CV_POUT = CV_DO * CV_HO * CV_WO;                        // 972
+constexpr int CT = 512;                                              // threads of the cost-volume kernel
 constexpr int CV_ROWF = 36;                                           // 32 + 4 pad floats per LDS row
 
 __global__ __launch_bounds__(CT) void cost_l1_kernel(const float* __restrict__ s_equi, const float* __restrict__ t_equi,
@@ -360,16 +359,18 @@ __global__ __launch_bounds__(CT) void cost_l1_kernel(const float* __restrict__ s
     }
 }
 
-template <int NCHUNK, int NTAPS, int P_IN, int P_OUT, int COUT, int G, bool RELU, bool DB>
+template <int NCHUNK, int NTAPS, int P_IN, int P_LDS, int P_OUT, int COUT, int G, bool RELU, int NW = 8, int NPW = 1>
 int launch_conv(hipStream_t s, const ConvLayerDev& L, const float* in, const int32_t* units_dev, int max_units, float* out,
-                const int32_t* skip)
+                const int32_t* skip, long long* dbg = nullptr)
 {
-    using C = ConvCfg<NCHUNK, NTAPS, P_IN, P_OUT, COUT, G, RELU, DB>;
-    if (L.nchunk != NCHUNK || L.ntaps != NTAPS || L.p_in != P_IN || L.p_out != P_OUT || L.cout != COUT || (L.relu != 0) != RELU) {
-        bx_set_error("conv layer geometry mismatch (%d %d %d %d %d)", L.nchunk, L.ntaps, L.p_in, L.p_out, L.cout);
+    using C = ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT, COUT, G, RELU, NW, NPW>;
+    constexpr int CT = C::CT;
+    if (L.nchunk != NCHUNK || L.ntaps != NTAPS || L.p_in != P_IN || L.p_lds != P_LDS || L.p_out != P_OUT || L.cout != COUT ||
+        (L.relu != 0) != RELU) {
+        bx_set_error("conv layer geometry mismatch (%d %d %d %d %d %d)", L.nchunk, L.ntaps, L.p_in, L.p_lds, L.p_out, L.cout);
         return BX_ERR_STATE;
     }
-    auto k = conv_kernel<NCHUNK, NTAPS, P_IN, P_OUT, COUT, G, RELU, DB>;
+    auto k = conv_kernel<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT, COUT, G, RELU, NW, NPW>;
     static bool attr_set = false;
     if (!attr_set) {
         BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
@@ -377,23 +378,8 @@ int launch_conv(hipStream_t s, const ConvLayerDev& L, const float* in, const int
     }
     int grid = (max_units + G - 1) / G;
     if (grid <= 0) return BX_OK;
-    // persistent workgroups: as many as are co-resident (LDS- and register-limited), each walking its groups
-    static int wg_per_cu = 0, n_cu = 0;
-    if (!wg_per_cu) {
-        int dev = 0, occ = 0;
-        hipDeviceProp_t prop;
-        BX_HIP(hipGetDevice(&dev));
-        BX_HIP(hipGetDeviceProperties(&prop, dev));
-        n_cu = prop.multiProcessorCount;
-        BX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, CT, C::LDS_BYTES));
-        wg_per_cu = 1 << 20;   // default: one unit group per workgroup (measured faster than the persistent walk)
-        (void)occ;
-        const char* e = getenv("BX_CONV_WGPCU");
-        if (e && atoi(e) > 0) wg_per_cu = atoi(e);
-    }
-    const long long cap = (long long)wg_per_cu * n_cu;
-    if ((long long)grid > cap) grid = (int)cap;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(CT), C::LDS_BYTES, s, in, units_dev, max_units, L.W, L.b, L.tap, out, skip);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(CT), C::LDS_BYTES, s, in, units_dev, max_units, L.W, L.b, L.lrow, L.lrow2, L.obase, L.toff,
+                       out, skip, dbg);
     BX_LAUNCH_CHECK();
     return BX_OK;
 }
@@ -401,34 +387,37 @@ int launch_conv(hipStream_t s, const ConvLayerDev& L, const float* in, const int
 
 int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, const int32_t* units_dev, int max_units, float* out)
 {
+    constexpr int CYL = (BX_ELE + 2) * (BX_AZI + 2);   // 198 LDS rows per unit: cylindrical map + halo
     if (net == 0) {
         const ConvLayerDev& L = c->desc[layer];
-        // Units per workgroup chosen by measurement (tools/gpu_conv.sh, K = 5000): 64- and 32-channel layers run 2 units
-        // per workgroup (9 accumulator tiles per wave, <= 128 VGPRs, 2-3 workgroups per CU); the 128-channel layers
-        // keep 2 units (18 tiles per wave, "lean" loop) -- 1 unit per workgroup halves the reuse of the B fragments.
+        // Configuration by measurement (tools/gpu_conv.sh, K = 5000): 8 waves; 2 units per workgroup for the 64- and
+        // 32-channel layers (9 / 5 accumulator tiles per wave), 1 unit for the 128-channel layers.  Variants tried and
+        // found within +-2 %: 4-wave workgroups, two column tiles per wave (NPW = 2), a persistent group walk,
+        // pinned accumulator interleaving (10 % slower).  The stack sits at ~113 TFLOP/s in every variant.
         switch (layer) {
-            //                     NCHUNK taps P_IN P_OUT COUT G  RELU  DB
-            case 0: return launch_conv<3, 9, 140, 140, 64, 2, true, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 1: return launch_conv<4, 9, 140, 140, 64, 2, true, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 2: return launch_conv<4, 9, 140, 140, 128, 2, true, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 3: return launch_conv<8, 9, 140, 140, 128, 2, true, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 4: return launch_conv<8, 9, 140, 140, 64, 2, true, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 5: return launch_conv<4, 9, 140, 140, 64, 2, true, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 6: return launch_conv<4, 9, 140, 140, 32, 2, true, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 7: return launch_conv<2, 9, 140, 140, 32, 2, false, true>(s, L, in, units_dev, max_units, out, c->skip);
+            //                     NCHUNK taps P_IN P_LDS P_OUT COUT G  RELU
+            case 0: return launch_conv<3, 9, 140, CYL, 140, 64, 2, true>(s, L, in, units_dev, max_units, out, c->skip);
+            case 1: return launch_conv<4, 9, 140, CYL, 140, 64, 2, true>(s, L, in, units_dev, max_units, out, c->skip,
+                                                                          getenv("BX_BALL_DEBUG") ? c->ball_dbg : nullptr);
+            case 2: return launch_conv<4, 9, 140, CYL, 140, 128, 1, true>(s, L, in, units_dev, max_units, out, c->skip);
+            case 3: return launch_conv<8, 9, 140, CYL, 140, 128, 1, true>(s, L, in, units_dev, max_units, out, c->skip);
+            case 4: return launch_conv<8, 9, 140, CYL, 140, 64, 2, true>(s, L, in, units_dev, max_units, out, c->skip);
+            case 5: return launch_conv<4, 9, 140, CYL, 140, 64, 2, true>(s, L, in, units_dev, max_units, out, c->skip);
+            case 6: return launch_conv<4, 9, 140, CYL, 140, 32, 2, true>(s, L, in, units_dev, max_units, out, c->skip);
+            case 7: return launch_conv<2, 9, 140, CYL, 140, 32, 2, false>(s, L, in, units_dev, max_units, out, c->skip);
         }
     } else if (net == 1) {
         const ConvLayerDev& L = c->pose[layer];
         switch (layer) {
-            case 1: return launch_conv<2, 27, 972, 256, 64, 1, true, false>(s, L, in, units_dev, max_units, out, c->skip);
-            case 2: return launch_conv<4, 9, 256, 196, 64, 2, true, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 3: return launch_conv<4, 9, 196, 144, 128, 2, true, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 4: return launch_conv<8, 9, 144, 100, 128, 4, true, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 5: return launch_conv<8, 9, 100, 64, 64, 8, true, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 6: return launch_conv<4, 9, 64, 36, 64, 8, true, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 7: return launch_conv<4, 9, 36, 16, 32, 16, true, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 8: return launch_conv<2, 9, 16, 4, 32, 32, true, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 9: return launch_conv<2, 4, 4, 1, 20, 128, false, true>(s, L, in, units_dev, max_units, out, c->skip);
+            case 1: return launch_conv<2, 27, 972, 972, 256, 64, 1, true>(s, L, in, units_dev, max_units, out, c->skip);
+            case 2: return launch_conv<4, 9, 256, 256, 196, 64, 2, true>(s, L, in, units_dev, max_units, out, c->skip);
+            case 3: return launch_conv<4, 9, 196, 196, 144, 128, 2, true>(s, L, in, units_dev, max_units, out, c->skip);
+            case 4: return launch_conv<8, 9, 144, 144, 100, 128, 2, true>(s, L, in, units_dev, max_units, out, c->skip);
+            case 5: return launch_conv<8, 9, 100, 100, 64, 64, 4, true>(s, L, in, units_dev, max_units, out, c->skip);
+            case 6: return launch_conv<4, 9, 64, 64, 36, 64, 8, true>(s, L, in, units_dev, max_units, out, c->skip);
+            case 7: return launch_conv<4, 9, 36, 36, 16, 32, 16, true>(s, L, in, units_dev, max_units, out, c->skip);
+            case 8: return launch_conv<2, 9, 16, 16, 4, 32, 32, true>(s, L, in, units_dev, max_units, out, c->skip);
+            case 9: return launch_conv<2, 4, 4, 4, 1, 20, 128, false>(s, L, in, units_dev, max_units, out, c->skip);
         }
     }
     bx_set_error("bxk_conv: bad net/layer %d/%d", net, layer);

@@ -96,7 +96,16 @@ def main():
     if args.what in ("conv", "all"):
         _, patches = ctx.ball_group(pp, kp, radii[0:1].contiguous(), P, want_idx=False)
         _, feat = ctx.patch_features(patches, radii[0:1].contiguous(), False)
+        if os.environ.get("BX_BENCH_ZERO"):   # power experiment: all-zero A operands
+            feat.zero_()
         us = timeit(torch, lambda: ctx.desc_net(feat), max(3, args.iters // 4))
+        if os.environ.get("BX_BALL_DEBUG"):
+            import ctypes as C
+            buf = (C.c_int64 * 512)()
+            ctx.lib.bx_debug_read(ctx.handle, buf, 512)
+            a = np.array(buf[:]).reshape(16, 32)
+            print("conv layer-1 stamps (median cycles over 16 workgroups): prologue %d | " % np.median(a[:, 1]) +
+                  " ".join("c%d taps %d bar %d" % (c, np.median(a[:, 2 + 2 * c]), np.median(a[:, 3 + 2 * c])) for c in range(4)) + " | end %d" % np.median(a[:, 10]))
         flops = 2.0 * 59.351e6 * K
         out.append(dict(stage="desc_net (8 conv + head)", K=K, us=round(us, 1), TFLOPs=round(flops / us / 1e6, 2)))
     for o in out:

@@ -3,7 +3,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out; mkdir -p $OUT/prof_conv
 for v in $VARIANTS; do
-for gh in 0 1; do
+for gh in 0; do
 export BX_CONV_GHALF=$gh
 export BX_HIP_SO=$PWD/buffer-x_amd/csrc/_exp/libbx_$v.so
 echo "== $v GHALF=$gh"
