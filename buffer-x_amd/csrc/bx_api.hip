@@ -36,6 +36,26 @@ struct ProfScope {
     }
 };
 
+}  // namespace
+
+// event bracket usable from the other translation units (tag 12 = the neighbour-gather query kernel alone)
+void bx_prof_mark(bx_ctx* c, hipStream_t s, int tag, int begin)
+{
+    if (!c->prof_on) return;
+    static thread_local ProfEvt cur;
+    if (begin) {
+        cur.tag = tag;
+        if (hipEventCreate(&cur.a) != hipSuccess || hipEventCreate(&cur.b) != hipSuccess) { cur.tag = -1; return; }
+        (void)hipEventRecord(cur.a, s);
+    } else if (cur.tag == tag) {
+        (void)hipEventRecord(cur.b, s);
+        static_cast<std::vector<ProfEvt>*>(c->prof)->push_back(cur);
+        cur.tag = -1;
+    }
+}
+
+namespace {
+
 struct Carver {
     char* base;
     size_t off;
@@ -61,6 +81,7 @@ void carve(bx_ctx* c, char* base, size_t* total)
     c->act0 = cv.take<float>(act);
     c->act1 = cv.take<float>(act);
     c->patches = cv.take<float>(K * P * 3);
+    c->ball_idx = cv.take<int32_t>(K * P);
     c->feat = cv.take<float>(K * BX_RAD * BX_EA * 16);
     c->pts_perm = cv.take<float>(NMAX * 3);
     for (int i = 0; i < 2; ++i) {
@@ -462,6 +483,7 @@ int bx_ball_group(bx_ctx* c, void* stream, const float* pts_perm, int32_t n, con
     if ((rc = check_ctx(c, false)) != BX_OK) return rc;
     if (!pts_perm || !kpts || !radius || !patches_out) { bx_set_error("bx_ball_group: null argument"); return BX_ERR_ARG; }
     c->skip = nullptr;
+    c->ball_waves_hint = 0;
     return bxk_ball_group(c, (hipStream_t)stream, pts_perm, n, kpts, K, radius, P, idx_out, patches_out);
 }
 
@@ -593,7 +615,9 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
         { ProfScope ps(c, s, 1); if ((rc = bxk_radius_bisect(c, s, (int64_t)ns[big], NK, p.search_radius_thresholds[i], &st->des_r[i])) != BX_OK) return rc; }
         for (int cl = 0; cl < 2; ++cl) {
             { ProfScope ps(c, s, 11); if ((rc = bx_permute_launch(s, clouds[cl], perms[cl] + (size_t)i * ns[cl], ns[cl], c->pts_perm, c->skip)) != BX_OK) return rc; }
-            { ProfScope ps(c, s, 2); if ((rc = bxk_ball_group(c, s, c->pts_perm, ns[cl], c->kpts[cl], K, &st->des_r[i], P, nullptr, c->patches)) != BX_OK) return rc; }
+            // expected neighbourhood = threshold % of the cloud: large ones get 4 waves per keypoint, small ones 2 (measured)
+            c->ball_waves_hint = p.search_radius_thresholds[i] >= 1.5 ? 4 : 2;
+            { ProfScope ps(c, s, 2); if ((rc = bxk_ball_group(c, s, c->pts_perm, ns[cl], c->kpts[cl], K, &st->des_r[i], P, c->ball_idx, c->patches)) != BX_OK) return rc; }
             { ProfScope ps(c, s, 3); if ((rc = bxk_patch_features(c, s, c->patches, K, P, &st->des_r[i], aligned_z, c->Rpatch[cl], c->feat)) != BX_OK) return rc; }
             { ProfScope ps(c, s, 4); if ((rc = desc_stack(c, s, c->feat, K, c->desc_out[cl], c->equi[cl], nullptr)) != BX_OK) return rc; }
         }

@@ -68,6 +68,7 @@ struct BallGrid {
 };
 // tuning knob (env BX_BALL_DIV, read once): cell edge = padded radius / div  (1..3)
 int bx_ball_div();
+void bx_prof_mark(bx_ctx* c, hipStream_t s, int tag, int begin);   // hipEvent bracket (bx_profile_*), no-op unless enabled
 
 struct bx_ctx {
     int device;
@@ -88,6 +89,7 @@ struct bx_ctx {
     // carved buffers (see bx_api.hip)
     float *act0, *act1;                 // conv ping-pong
     float* patches;                     // [K][P][3]
+    int32_t* ball_idx;                  // [K][P] ball_query indices (the reference op's first output; kept for parity of the op)
     float* feat;                        // [K][3][140][16]
     float* pts_perm;                    // [max_points][3]
     int32_t* fps_idx[2];                // per cloud [max(K,nk)]
@@ -119,7 +121,8 @@ struct bx_ctx {
     int32_t* ball_bsum;                 // per scan tile
     int2* ball_cellrank;                // [max_points]
     float4 *ball_pts4, *ball_sorted;    // [max_points] {x,y,z,0} in permuted order / {x,y,z,bits(i)} sorted by cell
-    int ball_attr_set;
+    long long ball_attr_set;
+    int ball_waves_hint;                // waves per keypoint of the next neighbour-gather launch (0 = default 2)
     long long* ball_dbg;                // [64][8] cycle stamps (BX_BALL_DEBUG)
     PairState* state;                   // device
     bx_result* result_dev;              // device staging of the result

@@ -9,12 +9,12 @@
 //   1. a uniform grid with cell edge h >= r(1+pad) is built over the permuted cloud per launch (the radius only
 //      exists on the device): bbox -> counting sort by cell (atomic rank, 2-kernel scan, scatter).  A sorted
 //      entry is {x, y, z, bits(i)} with i = position in the permuted cloud, one 16-byte load per candidate.
-//   2. query: ONE wave per keypoint (64-thread workgroups, no barriers across waves).  The wave walks the <= 3x3
-//      (y,z) cell rows around the keypoint; a row's <= 3 x-cells are ONE contiguous range of the sorted array, so
-//      candidates stream in with coalesced 16-B loads.  Every hit sets bit i of an n-bit bitmap in LDS
+//   2. query: one 4-wave workgroup per keypoint.  The (y,z) cell rows around the keypoint are laid end to end into one
+//      flat candidate sequence (a row's x-cells are ONE contiguous range of the sorted array), so candidates stream
+//      in with coalesced 16-B loads, 8 in flight per lane.  Every hit sets bit i of an n-bit bitmap in LDS
 //      (ds_or_b32).  The bitmap restores the reference's order for free: set bits in increasing i ARE the
 //      ball_query output order, whatever order the candidates were visited in.
-//   3. ordered expansion: lane w owns bitmap word w of a 64-word group; popcount + wave prefix gives each lane the
+//   3. ordered expansion: every thread owns a run of bitmap words; popcount + prefix over the workgroup gives it the
 //      output rank of its first hit; it peels its bits (ctz) into an LDS index list, stopping at P.
 //   4. output: lane j reads list[j], gathers {x,y,z} with one 16-B load from the float4 copy of the cloud
 //      (L2 resident), applies the mask arithmetic and stores 12 contiguous bytes (global_store_dwordx3) -- a wave
@@ -258,32 +258,26 @@ struct F3 { float x, y, z; };   // 4-byte aligned triple: stores compile to glob
 constexpr int QU = 8;            // candidate loads in flight per lane
 constexpr int MAXROWS = 63;      // (y,z) cell rows kept in the per-wave row table (one lane each)
 
-// Bit i of the hit bitmap: lane (i>>6)>>LOGC owns the 64<<LOGC consecutive indices starting at lane*(64<<LOGC);
-// its slot-th 64-bit word sits at bm64[slot*64 + lane] (conflict-free for the owner's ds_read_b64 sweep).
-template <int LOGC>
+// QW waves per workgroup, ONE keypoint per workgroup (template parameter: 4 / 2 / 1 by the expected neighbourhood size)
+
+// Bit i of the hit bitmap: thread (i>>6) / CW owns CW = (1<<LOGC)/QW consecutive 64-bit words; its slot-th word sits at
+// bm64[slot*QT + thread] (conflict-free for the owners' ds_read_b64 sweep).
+template <int LOGC, int QW>
 __device__ __forceinline__ void set_hit(unsigned int* bm32, int i)
 {
+    constexpr int LQW = QW == 4 ? 2 : (QW == 2 ? 1 : 0);
+    constexpr int LCW = LOGC - LQW;               // log2(CW)
     const int w = i >> 6;
-    const int a64 = ((w & ((1 << LOGC) - 1)) << 6) + (w >> LOGC);
+    const int a64 = ((w & ((1 << LCW) - 1)) << (6 + LQW)) + (w >> LCW);
     atomicOr(&bm32[a64 * 2 + ((i >> 5) & 1)], 1u << (i & 31));
 }
 
-// One wave per keypoint.  LOGC: log2 of the 64-bit bitmap words per lane (n <= 4096 << LOGC).
-// LDS: max(bitmap, index list) -- the list overwrites the bitmap once every lane holds its words in registers.
-// wave-local ordering of LDS traffic: a wave's DS instructions execute in program order, so cross-lane hand-offs
-// inside ONE wave only need the compiler not to reorder them (no s_barrier: the four waves of a workgroup are
-// independent keypoints and never wait for each other)
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-constexpr int QW = 4;            // waves (= keypoints) per workgroup
-
-template <int LOGC>
-__global__ __launch_bounds__(64 * QW) void ball_query_kernel(const float4* __restrict__ sorted, const int32_t* __restrict__ start,
+// One 4-wave workgroup per keypoint (one wave per keypoint left the kernel waiting for its slowest keypoints: the
+// candidate count varies 3x between keypoints; four waves per keypoint and 3-4 workgroup rounds even that out).
+// LOGC: log2 of the 64-bit bitmap words per 64 lanes (n <= 4096 << LOGC).  LDS: max(bitmap, index list) -- the list
+// overwrites the bitmap once every thread holds its words in registers.
+template <int LOGC, int QW>
+__global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __restrict__ sorted, const int32_t* __restrict__ start,
                                                         const BallGrid* __restrict__ g, const float4* __restrict__ pts4,
                                                         const float* __restrict__ kpts, int K,
                                                         const double* __restrict__ radius, int P, int32_t* __restrict__ idx_out,
@@ -291,24 +285,23 @@ __global__ __launch_bounds__(64 * QW) void ball_query_kernel(const float4* __res
                                                         long long* __restrict__ dbg)
 {
     if (skip && *skip) return;
+    constexpr int QT = 64 * QW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int wtot[QW];
     long long t0 = 0;
-    const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * QW + (threadIdx.x >> 6);
-    if (q >= K) return;
-    const bool tr = dbg != nullptr && (q % 79) == 0 && q / 79 < 60;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x;
+    const bool tr = dbg != nullptr && (q % 79) == 0 && q / 79 < 60 && tid == 0;
     long long* td = dbg + (q / 79) * 8;
     if (tr) { t0 = __builtin_readcyclecounter(); td[0] = t0; }
 #define BX_TR(k) do { if (tr) td[k] = __builtin_readcyclecounter() - t0; } while (0)
-    constexpr int C = 1 << LOGC;
-    const size_t wbytes = ((size_t)C * 512 > (size_t)P * 4) ? (size_t)C * 512 : (size_t)P * 4;
-    char* wmem = smem + (threadIdx.x >> 6) * wbytes;   // this wave's private slice
-    unsigned long long* bm64 = reinterpret_cast<unsigned long long*>(wmem);
-    unsigned int* bm32 = reinterpret_cast<unsigned int*>(wmem);
-    int* list = reinterpret_cast<int*>(wmem);           // [P], aliases the bitmap (see the hand-off below)
+    constexpr int CW = (1 << LOGC) / QW;                // bitmap words per thread
+    unsigned long long* bm64 = reinterpret_cast<unsigned long long*>(smem);
+    unsigned int* bm32 = reinterpret_cast<unsigned int*>(smem);
+    int* list = reinterpret_cast<int*>(smem);           // [P], aliases the bitmap (see the hand-off below)
 
 #pragma unroll
-    for (int s = 0; s < C; ++s) bm64[s * 64 + lane] = 0ULL;
+    for (int s = 0; s < CW; ++s) bm64[s * QT + tid] = 0ULL;
 
     const float r = (float)(*radius);
     const float r2 = r * r;
@@ -321,12 +314,13 @@ __global__ __launch_bounds__(64 * QW) void ball_query_kernel(const float4* __res
     const int ny = yhi - ylo + 1, nz = zhi - zlo + 1;
     const int R = ny * nz;
     BX_TR(1);
+    __syncthreads();                                        // bitmap zeroed
 
     if (R <= MAXROWS) {
         // ---- row table: every (y,z) row of cells is one contiguous range of the sorted array; the rows are laid end
-        //      to end into ONE flat candidate sequence so that all 64 lanes and QU loads per lane stay busy.  Lane k
-        //      keeps row k's flat end offset (pe) and its sorted-array offset minus its flat start (rs); a 64-candidate
-        //      chunk finds its rows with wave-uniform readlanes (no LDS, no per-lane search).
+        //      to end into ONE flat candidate sequence.  Lane k of every wave keeps row k's flat end offset (pe) and
+        //      its sorted-array offset minus its flat start (rs); a 64-candidate chunk finds its rows with wave-uniform
+        //      readlanes (no LDS, no per-lane search).  The four waves take the 64*QU-candidate blocks round-robin.
         int s_r = 0, len = 0;
         if (lane < R) {
             const int cz = zlo + lane / ny, cy = ylo + lane % ny;
@@ -338,11 +332,10 @@ __global__ __launch_bounds__(64 * QW) void ball_query_kernel(const float4* __res
         const int T = __builtin_amdgcn_readlane(inc, 63);
         const int rs = s_r - (inc - len);
         const int pe = lane < R ? inc : 0x7fffffff;
-        wave_sync();
         BX_TR(2);
         if (tr) td[7] = T;
         int rb = 0;                                         // wave-uniform: first row whose end lies beyond the chunk start
-        for (int v0 = 0; v0 < T; v0 += 64 * QU) {
+        for (int v0 = wave * 64 * QU; v0 < T; v0 += QW * 64 * QU) {
             float4 c[QU];
 #pragma unroll
             for (int u = 0; u < QU; ++u) {
@@ -367,42 +360,49 @@ __global__ __launch_bounds__(64 * QW) void ball_query_kernel(const float4* __res
             for (int u = 0; u < QU; ++u) {
                 const float ax = qx - c[u].x, ay = qy - c[u].y, az = qz - c[u].z;
                 const float d2 = (ax * ax + ay * ay) + az * az;
-                if (d2 < r2) set_hit<LOGC>(bm32, __float_as_int(c[u].w));
+                if (d2 < r2) set_hit<LOGC, QW>(bm32, __float_as_int(c[u].w));
             }
         }
     } else {
         // degenerate geometry (cell edge << radius because of the 1024-cells-per-axis floor): plain nested walk
-        wave_sync();
+        int rowi = 0;
         for (int cz = zlo; cz <= zhi; ++cz)
-            for (int cy = ylo; cy <= yhi; ++cy) {
+            for (int cy = ylo; cy <= yhi; ++cy, ++rowi) {
+                if ((rowi & (QW - 1)) != wave) continue;
                 const int rowc = (cz * dy + cy) * dx;
                 const int s = start[rowc + xlo], e = start[rowc + xhi + 1];
                 for (int k = s + lane; k < e; k += 64) {
                     const float4 a = sorted[k];
                     const float ax = qx - a.x, ay = qy - a.y, az = qz - a.z;
                     const float d2 = (ax * ax + ay * ay) + az * az;
-                    if (d2 < r2) set_hit<LOGC>(bm32, __float_as_int(a.w));
+                    if (d2 < r2) set_hit<LOGC, QW>(bm32, __float_as_int(a.w));
                 }
             }
     }
-    wave_sync();
+    __syncthreads();
     BX_TR(3);
 
-    // ---- ordered expansion of the first P set bits: lane l owns indices [l*64C, (l+1)*64C); its words move to
+    // ---- ordered expansion of the first P set bits: thread t owns indices [t*64*CW, (t+1)*64*CW); its words move to
     //      registers, then the index list is written over the bitmap
-    unsigned long long word[C];
+    unsigned long long word[CW];
     int tot = 0;
 #pragma unroll
-    for (int s = 0; s < C; ++s) { word[s] = bm64[s * 64 + lane]; tot += __popcll(word[s]); }
+    for (int s = 0; s < CW; ++s) { word[s] = bm64[s * QT + tid]; tot += __popcll(word[s]); }
     const int inc = bx_wave_incl_scan_dpp(tot);
-    const int run = __builtin_amdgcn_readlane(inc, 63);
-    wave_sync();                                            // every lane has read its bitmap words
-    int pos = inc - tot;
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();                                        // every thread has read its bitmap words; wave totals visible
+    int pos = inc - tot, run = 0;
+#pragma unroll
+    for (int w = 0; w < QW; ++w) {
+        const int wt = wtot[w];
+        if (w < wave) pos += wt;
+        run += wt;
+    }
     if (tot > 0 && pos < P) {
 #pragma unroll
-        for (int s = 0; s < C; ++s) {
+        for (int s = 0; s < CW; ++s) {
             unsigned long long w = word[s];
-            const int base = ((lane << LOGC) + s) << 6;
+            const int base = (tid * CW + s) << 6;
             while (w != 0ULL && pos < P) {
                 const int b = __ffsll((long long)w) - 1;
                 list[pos++] = base + b;
@@ -411,27 +411,27 @@ __global__ __launch_bounds__(64 * QW) void ball_query_kernel(const float4* __res
         }
     }
     const int nhit = run < P ? run : P;
-    wave_sync();
+    __syncthreads();
     BX_TR(4);
 
     // ---- output: gather + mask arithmetic (models/patch_embedder.py:105-111), 768 contiguous bytes per wave store
     const int first = nhit > 0 ? list[0] : 0;
     F3* out3 = reinterpret_cast<F3*>(patches) + (size_t)q * P;
     int32_t* outi = idx_out ? idx_out + (size_t)q * P : nullptr;
-    constexpr int OU = 8;
-    for (int j0 = 0; j0 < P; j0 += 64 * OU) {
+    constexpr int OU = 4;
+    for (int j0 = 0; j0 < P; j0 += QT * OU) {
         int idx[OU];
         float4 p[OU];
 #pragma unroll
         for (int u = 0; u < OU; ++u) {
-            const int j = j0 + u * 64 + lane;
+            const int j = j0 + u * QT + tid;
             idx[u] = j < nhit ? list[j] : first;
         }
 #pragma unroll
         for (int u = 0; u < OU; ++u) p[u] = pts4[idx[u]];
 #pragma unroll
         for (int u = 0; u < OU; ++u) {
-            const int j = j0 + u * 64 + lane;
+            const int j = j0 + u * QT + tid;
             if (j < P) {
                 float mask = (idx[u] == first) ? 1.0f : 0.0f;
                 if (j == 0) mask = 0.0f;
@@ -450,20 +450,33 @@ __global__ __launch_bounds__(64 * QW) void ball_query_kernel(const float4* __res
     if (tr) { __builtin_amdgcn_s_waitcnt(0); td[6] = __builtin_readcyclecounter() - t0; }
 }
 
-template <int LOGC>
-int launch_query(bx_ctx* c, hipStream_t s, int K, const float* kpts, const double* radius, int P, int32_t* idx_out, float* patches_out)
+template <int LOGC, int QW>
+int launch_query_w(bx_ctx* c, hipStream_t s, int K, const float* kpts, const double* radius, int P, int32_t* idx_out, float* patches_out)
 {
     const size_t bm = ((size_t)64 << LOGC) * 8, li = (size_t)P * 4;
-    const size_t lds = (bm > li ? bm : li) * QW;
+    const size_t lds = bm > li ? bm : li;
     if (lds > 160 * 1024) { bx_set_error("bxk_ball_group: P=%d needs %zu B of LDS per keypoint (> 160 KiB)", P, lds); return BX_ERR_ARG; }
-    if (lds > 64 * 1024 && !(c->ball_attr_set & (1 << LOGC))) {
-        BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_kernel<LOGC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        c->ball_attr_set |= 1 << LOGC;
+    if (lds > 64 * 1024 && !(c->ball_attr_set & (1LL << (LOGC * 3 + QW / 2)))) {
+        BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_kernel<LOGC, QW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        c->ball_attr_set |= 1 << (LOGC * 3 + QW / 2);
     }
-    hipLaunchKernelGGL(ball_query_kernel<LOGC>, dim3((K + QW - 1) / QW), dim3(64 * QW), lds, s, c->ball_sorted, c->ball_start, c->ball_grid, c->ball_pts4, kpts, K,
+    hipLaunchKernelGGL((ball_query_kernel<LOGC, QW>), dim3(K), dim3(64 * QW), lds, s, c->ball_sorted, c->ball_start, c->ball_grid, c->ball_pts4, kpts, K,
                        radius, P, idx_out, patches_out, c->skip, getenv("BX_BALL_DEBUG") ? c->ball_dbg : nullptr);
     BX_LAUNCH_CHECK();
     return BX_OK;
+}
+
+template <int LOGC>
+int launch_query(bx_ctx* c, hipStream_t s, int K, const float* kpts, const double* radius, int P, int32_t* idx_out, float* patches_out)
+{
+    // waves per keypoint: 4 for the large neighbourhoods (their candidate scan dominates), 1 for the small ones (the
+    // per-keypoint chain of dependent memory round trips dominates and more independent workgroups hide it better)
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("BX_BALL_WAVES"); forced = e ? atoi(e) : 0; }
+    const int w = forced ? forced : c->ball_waves_hint;
+    if (w >= 4) return launch_query_w<LOGC, 4>(c, s, K, kpts, radius, P, idx_out, patches_out);
+    if (w == 1) return launch_query_w<LOGC, 1>(c, s, K, kpts, radius, P, idx_out, patches_out);
+    return launch_query_w<LOGC, 2>(c, s, K, kpts, radius, P, idx_out, patches_out);
 }
 }  // namespace
 
@@ -507,12 +520,16 @@ int bxk_ball_group(bx_ctx* c, hipStream_t s, const float* pts_perm, int n, const
     hipLaunchKernelGGL(scan_sums_kernel, dim3(ntile), dim3(256), 0, s, c->ball_cnt, c->ball_grid, c->ball_bsum, skip);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(ntile), dim3(256), 0, s, c->ball_cnt, c->ball_grid, c->ball_bsum, c->ball_start, skip);
     hipLaunchKernelGGL(cell_scatter_kernel, dim3(nb), dim3(256), 0, s, c->ball_pts4, n, c->ball_cellrank, c->ball_start, c->ball_sorted, skip);
+    bx_prof_mark(c, s, 12, 1);
+    int rc = BX_OK;
     switch (logc) {
-    case 3: return launch_query<3>(c, s, K, kpts, radius, P, idx_out, patches_out);
-    case 4: return launch_query<4>(c, s, K, kpts, radius, P, idx_out, patches_out);
-    case 5: return launch_query<5>(c, s, K, kpts, radius, P, idx_out, patches_out);
-    case 6: return launch_query<6>(c, s, K, kpts, radius, P, idx_out, patches_out);
-    case 7: return launch_query<7>(c, s, K, kpts, radius, P, idx_out, patches_out);
-    default: return launch_query<8>(c, s, K, kpts, radius, P, idx_out, patches_out);
+    case 3: rc = launch_query<3>(c, s, K, kpts, radius, P, idx_out, patches_out); break;
+    case 4: rc = launch_query<4>(c, s, K, kpts, radius, P, idx_out, patches_out); break;
+    case 5: rc = launch_query<5>(c, s, K, kpts, radius, P, idx_out, patches_out); break;
+    case 6: rc = launch_query<6>(c, s, K, kpts, radius, P, idx_out, patches_out); break;
+    case 7: rc = launch_query<7>(c, s, K, kpts, radius, P, idx_out, patches_out); break;
+    default: rc = launch_query<8>(c, s, K, kpts, radius, P, idx_out, patches_out); break;
     }
+    bx_prof_mark(c, s, 12, 0);
+    return rc;
 }

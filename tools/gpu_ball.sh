@@ -4,9 +4,9 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out; mkdir -p $OUT
 rm -rf $OUT/prof_ball; mkdir -p $OUT/prof_ball
-for div in ${DIVS:-1 2 3}; do
-export BX_BALL_DIV=$div
-echo "=== BX_BALL_DIV=$div"
+for div in ${WAVES:-1 2 4}; do
+export BX_BALL_WAVES=$div
+echo "=== BX_BALL_WAVES=$div"
 timeout 600 python -m pytest tests/test_gpu_stages.py -x -q -k "ball" 2>&1 | tail -3
 for n in ${NS:-30000 60000}; do
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_ball/d${div}_n$n -o kt -- python tools/bench_stage.py ball --n $n > $OUT/prof_ball/bench_d${div}_$n.log 2>&1
