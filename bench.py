@@ -30,6 +30,17 @@ PEAK_HBM_GBS = 8000.0            # HBM3E spec (6.29 TB/s measured achievable)
 DESC_CONV_MMAC_PER_PATCH = 3.871 + 5.161 + 10.322 + 20.644 + 10.322 + 5.161 + 2.580 + 1.290
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the two roofline kernels from the committed rocprofv3 PMC passes of THIS command
+    (profiles/r01_pmc_traffic.json, derived by tools/pmc_traffic.py: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
+    --pmc runs as MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside the process; None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
 def make_inputs(bx, oracle_perm, n_pairs, base_seed, S):
     """Distinct seeded synthetic pairs with N ~ U[20k, 60k]."""
     pairs = []
@@ -168,11 +179,14 @@ def main():
         conv_ms, conv_n = stages.get("desc_conv", (0.0, 0))
         flops_per_stack = 2.0 * DESC_CONV_MMAC_PER_PATCH * 1e6 * K
         roof = None
+        pmc = pmc_traffic()
         if conv_n:
             ach = flops_per_stack / (conv_ms / conv_n * 1e-3) / 1e12
             roof = {"kernel": "conv_kernel<...> x8 (Cylindrical_Net stack, v_mfma_f32_16x16x4_f32)", "bound": "mfma",
                     "achieved": round(ach, 3), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_F32_MATRIX_TFLOPS, 4),
+                    "traffic": pmc["desc_conv_stack_bytes_per_launch"] if pmc else None,
+                    "traffic_note": "HBM bytes per stack launch, rocprofv3 PMC (profiles/r01_pmc_traffic.json); algorithmic in+out maps = 3.27e9",
                     "avg_launch_ms": round(conv_ms / conv_n, 4), "launches": conv_n,
                     "algorithmic_flops_per_launch": flops_per_stack,
                     "note": "hipEvent-timed, one pair in flight, %d pairs right after the timed region" % NPROF}
@@ -186,7 +200,8 @@ def main():
             nbytes = 12.0 * nmean + 12.0 * K + 4.0 * K * P + 12.0 * K * P
             ach = nbytes / (ng_ms / ng_n * 1e-3) / 1e9
             roof_ng = {"kernel": "ball_query_kernel", "bound": "hbm", "achieved": round(ach, 2), "peak": PEAK_HBM_GBS,
-                       "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                       "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
+                       "traffic": pmc["ball_query_bytes_per_launch"] if pmc else None,
                        "avg_launch_ms": round(ng_ms / ng_n, 4), "launches": ng_n, "algorithmic_bytes_per_launch": nbytes,
                        "stage_avg_ms_incl_grid_build": round(st_ms / st_n, 4) if st_n else None}
         out = {
