@@ -80,8 +80,10 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
 
     int units = max_units;
     if (units_dev) { int u = *units_dev; units = u < max_units ? u : max_units; }
-    const int u0 = blockIdx.x * G;
-    if (u0 >= units) return;
+    const int ngroups = (units + G - 1) / G;
+    if ((int)blockIdx.x >= ngroups) return;
+    int grp = blockIdx.x;            // persistent walk: groups blockIdx.x, blockIdx.x + gridDim.x, ...
+    int u0 = grp * G;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave % C::WN, wm = wave / C::WN;
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
     float4 st[C::NLD];
     // (the piece geometry is recomputed per chunk from an opaque copy of tid: keeping 3*NLD hoisted address registers
     //  alive across the MFMA loop costs the second co-resident workgroup on the 18-tile configurations)
-    auto piece = [&](int tq, int q, int& src, int& dst1, int& dst2) {
+    auto piece = [&](int tq, int q, int ub, int& src, int& dst1, int& dst2) {
         const int f = tq + q * CT;
         const int row = f >> 2, part = f & 3;
         const int g = row / P_IN, p = row - g * P_IN;
@@ -104,16 +106,16 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
             dst1 = (g * P_LDS + lrow[p]) * ROWF + part * 4;
             const int r2 = lrow2[p];
             if (r2 >= 0) dst2 = (g * P_LDS + r2) * ROWF + part * 4;
-            if (u0 + g < units) src = ((u0 + g) * NCHUNK * P_IN + p) * 4 + part;   // float4 index of chunk 0 (< 2^31 at these sizes)
+            if (ub + g < units) src = ((ub + g) * NCHUNK * P_IN + p) * 4 + part;   // float4 index of chunk 0 (< 2^31 at these sizes)
         }
     };
-    auto gload = [&](int cc) {
+    auto gload = [&](int cc, int ub) {
         int tq = tid;
         asm volatile("" : "+v"(tq));
 #pragma unroll
         for (int q = 0; q < C::NLD; ++q) {
             int src, d1, d2;
-            piece(tq, q, src, d1, d2);
+            piece(tq, q, ub, src, d1, d2);
             st[q] = src >= 0 ? in4[(size_t)src + (size_t)cc * P_IN * 4] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
 #pragma unroll
         for (int q = 0; q < C::NLD; ++q) {
             int src, d1, d2;
-            piece(tq, q, src, d1, d2);
+            piece(tq, q, 0, src, d1, d2);
             if (d1 >= 0) *reinterpret_cast<float4*>(d + d1) = st[q];
             if (d2 >= 0) *reinterpret_cast<float4*>(d + d2) = st[q];
         }
@@ -141,21 +143,20 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
     }
     const int toffv = lane < NTAPS ? toff[lane] * (ROWF * 4) : 0;
 
-    gload(0);
+    gload(0, u0);
     __syncthreads();          // zero fill complete before the first slab lands on top of it
     lwrite(0);
     __syncthreads();
 
-    // ---- accumulators start at the (BN-folded) bias; a wave owns NPW column tiles of 16 channels
+    // ---- a wave owns NPW column tiles of 16 channels; accumulators start at the (BN-folded) bias
     const int n0 = wn * NPW * 16;
     bool colok[NPW];
+    float bvs[NPW];
     f32x4 acc[C::TPW][NPW];
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
         colok[j] = (n0 + j * 16 + li) < COUT;
-        const float bv = colok[j] ? bias[n0 + j * 16 + li] : 0.0f;
-#pragma unroll
-        for (int t = 0; t < C::TPW; ++t) acc[t][j] = (f32x4){bv, bv, bv, bv};
+        bvs[j] = colok[j] ? bias[n0 + j * 16 + li] : 0.0f;
     }
 
     const float* wbase = W + (size_t)kk * COUT + n0 + li;
@@ -180,8 +181,17 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
     __builtin_amdgcn_s_waitcnt(0);
     CV_TR(1);
 
-    for (int cc = 0; cc < NCHUNK; ++cc) {
-        const char* lb = reinterpret_cast<const char*>(buf + (size_t)(cc & 1) * C::BUF_FLOATS);
+    const int slot = 4 * (li & 3) + (li >> 2);
+    int sl = 0;                      // running slab counter: LDS buffer = sl & 1
+  for (;;) {
+#pragma unroll
+    for (int j = 0; j < NPW; ++j)
+#pragma unroll
+        for (int t = 0; t < C::TPW; ++t) acc[t][j] = (f32x4){bvs[j], bvs[j], bvs[j], bvs[j]};
+    const int grp_next = grp + (int)gridDim.x;
+#pragma unroll 1
+    for (int cc = 0; cc < NCHUNK; ++cc, ++sl) {
+        const char* lb = reinterpret_cast<const char*>(buf + (size_t)(sl & 1) * C::BUF_FLOATS);
         // one tap: per tile ONE address add + ONE ds_read_b128 (issued two tiles ahead) + 4 back-to-back MFMAs
         auto do_tap = [&](int tp, const float (&b_)[NPW][4]) {
             const int tb = __builtin_amdgcn_readlane(toffv, tp);
@@ -225,7 +235,9 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
                 if (ctn >= NCHUNK * NTAPS) ctn -= NCHUNK * NTAPS;   // harmless extra fetch after the last chunk
                 loadB(ctn, bt[i]);
             }
-            if (cc + 1 < NCHUNK) gload(cc + 1);
+            // next slab: the next chunk of this group, or chunk 0 of this workgroup's NEXT group (its prologue disappears)
+            if (cc + 1 < NCHUNK) gload(cc + 1, u0);
+            else if (grp_next < ngroups) gload(0, grp_next * G);
             do_tap(T0, bc);
 #pragma unroll
             for (int i = 0; i < KT; ++i) do_tap(T0 + 1 + i, bt[i]);
@@ -235,20 +247,21 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
                 for (int i = 0; i < 4; ++i) bc[j][i] = bt[KT][j][i];
         }
         CV_TR(2 + 2 * cc);
-        if (cc + 1 < NCHUNK) lwrite((cc + 1) & 1);
+        if (cc + 1 < NCHUNK || grp_next < ngroups) lwrite((sl + 1) & 1);
         __syncthreads();
         CV_TR(3 + 2 * cc);
     }
 
-    // ---- epilogue: ReLU, store in chunk-slot order
-    const int slot = 4 * (li & 3) + (li >> 2);
+    // ---- epilogue of this group: ReLU, store in chunk-slot order (the next group's first slab is already in LDS)
+    int mrow0 = kk * 4;
+    asm volatile("" : "+v"(mrow0));   // keeps the 4*TPW store addresses out of the loop-invariant hoisting (VGPR budget)
 #pragma unroll
     for (int t = 0; t < C::TPW; ++t) {
         const int mt = wm + t * C::WM;
         if (mt >= C::MT) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            int m = mt * 16 + kk * 4 + r;
+            int m = mt * 16 + mrow0 + r;
             if (m < C::M) {
                 int g = m / P_OUT, pos = m - g * P_OUT;
                 if (u0 + g < units) {
@@ -263,6 +276,10 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
         }
     }
     CV_TR(2 + 2 * NCHUNK);
+    grp = grp_next;
+    if (grp >= ngroups) break;
+    u0 = grp * G;
+  }
 }
 
 // ---------------------------------------------------------------- CostNet layer 0 on the implicit cost volume
@@ -378,6 +395,21 @@ int launch_conv(hipStream_t s, const ConvLayerDev& L, const float* in, const int
     }
     int grid = (max_units + G - 1) / G;
     if (grid <= 0) return BX_OK;
+    // persistent workgroups: as many as are co-resident, each walking its unit groups (BX_CONV_PERSIST=0: one group each)
+    static int cap = -1;
+    if (cap < 0) {
+        cap = 1 << 30;
+        const char* e = getenv("BX_CONV_PERSIST");
+        if (!e || atoi(e) != 0) {
+            int dev = 0, occ = 0;
+            hipDeviceProp_t prop;
+            BX_HIP(hipGetDevice(&dev));
+            BX_HIP(hipGetDeviceProperties(&prop, dev));
+            BX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, CT, C::LDS_BYTES));
+            if (occ >= 1) cap = occ * prop.multiProcessorCount;
+        }
+    }
+    if (grid > cap) grid = cap;
     hipLaunchKernelGGL(k, dim3(grid), dim3(CT), C::LDS_BYTES, s, in, units_dev, max_units, L.W, L.b, L.lrow, L.lrow2, L.obase, L.toff,
                        out, skip, dbg);
     BX_LAUNCH_CHECK();

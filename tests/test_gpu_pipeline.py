@@ -81,3 +81,71 @@ def test_pair_larger_config_success(bx, packed, oracle):
     ref = PL.register_pair(pair["src"], pair["tgt"], packed, cfg, pair["aligned_z"], 9)
     assert (n_inl, n_mut, n_ind, scales) == tuple(ref[1:])
     assert np.array_equal(pose, np.asarray(ref[0], np.float64))
+
+
+def test_pair_kitti_scale_cloud(bx, packed, oracle):
+    """BASELINE configs[2] geometry at reduced keypoint count: ~50k-point outdoor LiDAR-like clouds (aligned to the
+    global z axis, outdoor match parameters incl. confidence 1.0), multi-workgroup FPS, the 16-words-per-lane
+    neighbour bitmap and the large-extent grid; bit-exact against the oracle."""
+    from oracle import pipeline as PL
+    cfg = bx.make_cfg("KITTI")
+    cfg.patch.num_fps, cfg.patch.num_points_per_patch, cfg.patch.num_scales = 160, 128, 2
+    cfg.patch.search_radius_thresholds = [2, 0.5]
+    cfg.patch.num_points_radius_estimate = 160
+    cfg.match.iter_n = 1500
+    pair = bx.synth.make_pair(5, "outdoor", voxel=0.04)
+    assert len(pair["src"]) > 40000 and pair["aligned_z"]
+    pose, n_inl, n_mut, n_ind, scales, _ = run_gpu(bx, packed, oracle, cfg, pair, 4)
+    ref = PL.register_pair(pair["src"], pair["tgt"], packed, cfg, pair["aligned_z"], 4)
+    assert (n_inl, n_mut, n_ind, scales) == tuple(ref[1:])
+    assert np.array_equal(pose, np.asarray(ref[0], np.float64))
+
+
+def test_full_size_properties(bx, packed, oracle):
+    """BASELINE configs[1] sizes (K = 5000, P = 1024, 3 scales, N ~ 45k): too large for the oracle pipeline in a test,
+    so the full-size run is checked through size-independent properties: determinism (two runs bit-identical),
+    FPS indices unique, every gathered neighbour inside the radius and in ascending cloud order, padding rule, and
+    spot checks of 40 keypoints' neighbour lists against a brute-force NumPy search."""
+    import torch
+    from bufferx_amd import lib
+    cfg = bx.make_cfg("3DMatch")
+    cfg.patch.num_fps, cfg.patch.num_points_per_patch, cfg.patch.num_scales = 5000, 1024, 3
+    cfg.patch.search_radius_thresholds = [5, 2, 0.5]
+    pair = bx.synth.make_pair(31, "indoor", n_target=45000)
+    K, P = 5000, 1024
+    ctx = lib.Context(cfg, max_points=max(len(pair["src"]), len(pair["tgt"])), device=0, packed_weights=packed)
+    S = 3
+    perm_s = np.stack([oracle.make_perm(len(pair["src"]), 1, 2 * i) for i in range(S)])
+    perm_t = np.stack([oracle.make_perm(len(pair["tgt"]), 1, 2 * i + 1) for i in range(S)])
+    r1 = ctx.register_pair(pair["src"], pair["tgt"], pair["aligned_z"], perm_s, perm_t, 1)
+    a = (list(r1.pose), r1.num_inliers, r1.num_mutual, r1.num_inlier_ind, r1.scales_used)
+    r2 = ctx.register_pair(pair["src"], pair["tgt"], pair["aligned_z"], perm_s, perm_t, 1)
+    assert a == (list(r2.pose), r2.num_inliers, r2.num_mutual, r2.num_inlier_ind, r2.scales_used)
+    assert r1.status == 0 and r1.scales_used == 3 and r1.num_mutual > 0
+    pts = pair["src"]
+    idx, kp = ctx.fps(pts, K)
+    idx = idx.cpu().numpy()
+    assert len(np.unique(idx)) == K and idx[0] == 0
+    assert np.array_equal(kp.cpu().numpy(), pts[idx])
+    pp = pts[perm_s[0]]
+    rad = float(r1.des_r[0])
+    nidx, patches = ctx.ball_group(pp, kp, torch.tensor([rad], dtype=torch.float64), P)
+    nidx, patches = nidx.cpu().numpy(), patches.cpu().numpy()
+    kpn = kp.cpu().numpy()
+    r2f = np.float32(rad) * np.float32(rad)
+    for q in np.random.default_rng(0).choice(K, 40, replace=False):
+        d = kpn[q] - pp
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        hits = np.nonzero(d2 < r2f)[0][:P]
+        exp = np.full(P, hits[0] if len(hits) else 0, np.int32)
+        exp[:len(hits)] = hits
+        assert np.array_equal(nidx[q], exp)
+    first = nidx[:, :1]
+    real = np.concatenate([np.ones((K, 1), bool), nidx[:, 1:] != first], 1)
+    real[:, P - 1] = False
+    assert np.array_equal(patches[real], pp[nidx[real]])
+    assert np.array_equal(patches[:, P - 1], kpn)
+    # ascending order among the real (non-padded) entries
+    inc = np.diff(nidx.astype(np.int64), axis=1)
+    assert np.all((inc > 0) | ~real[:, 1:] | ~real[:, :-1] | (np.arange(1, P)[None, :] == P - 1))
+    ctx.close()

@@ -3,9 +3,9 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out; mkdir -p $OUT/prof_conv
 timeout 900 python -m pytest tests/test_gpu_stages.py -x -q -k "conv or desc or pose" 2>&1 | tail -3
-for gh in ${GHS:-0}; do
-export BX_CONV_G1=$gh
-echo "== BX_CONV_G1=$gh"
+for gh in ${GHS:-1 0}; do
+export BX_CONV_PERSIST=$gh
+echo "== BX_CONV_PERSIST=$gh"
 rm -rf $OUT/prof_conv/g$gh
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_conv/g$gh -o kt -- python tools/bench_stage.py conv --iters 12 > $OUT/prof_conv/bench_$gh.log 2>&1
 grep '"stage"' $OUT/prof_conv/bench_$gh.log
