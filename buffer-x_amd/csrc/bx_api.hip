@@ -408,6 +408,22 @@ int bx_load_weights(bx_ctx* c, const bx_weights* w)
     if ((rc = upload(&c->d_pool_b2, w->pool_b2, 1)) != BX_OK) return rc;
     // Desc: Cylindrical_Net (models/patchnet.py:72-84)
     static const int dc[BX_NDESC][2] = {{3, 64}, {4, 64}, {4, 128}, {8, 128}, {8, 64}, {4, 64}, {4, 32}, {2, 32}};
+    // B-fragment order of the MFMA kernels: [chunk*taps][column tile][lane = kk*16 + li][4] with element i =
+    // W[chunk][tap][kk + 4 i][tile*16 + li] (zero beyond cout): one 16-byte load per lane feeds the 4 MFMAs of a tile
+    auto upload_w = [&](ConvLayerDev& L, const float* wsrc) -> int {
+        const int nct = L.nchunk * L.ntaps, nt = (L.cout + 15) / 16;
+        std::vector<float> wp((size_t)nct * nt * 64 * 4, 0.0f);
+        for (int ct = 0; ct < nct; ++ct)
+            for (int t = 0; t < nt; ++t)
+                for (int kk = 0; kk < 4; ++kk)
+                    for (int li = 0; li < 16; ++li)
+                        for (int i = 0; i < 4; ++i) {
+                            const int col = t * 16 + li;
+                            if (col < L.cout)
+                                wp[((((size_t)ct * nt + t) * 4 + kk) * 16 + li) * 4 + i] = wsrc[((size_t)ct * 16 + kk + 4 * i) * L.cout + col];
+                        }
+        return upload(&L.W, wp.data(), wp.size());
+    };
     const ConvGeo cg = cyl_geo();
     auto upload_geo = [&](ConvLayerDev& L, const ConvGeo& g) -> int {
         int r;
@@ -420,7 +436,7 @@ int bx_load_weights(bx_ctx* c, const bx_weights* w)
     for (int l = 0; l < BX_NDESC; ++l) {
         ConvLayerDev& L = c->desc[l];
         L.nchunk = dc[l][0]; L.ntaps = 9; L.p_in = BX_EA; L.p_out = BX_EA; L.cout = dc[l][1]; L.relu = l < BX_NDESC - 1;
-        if ((rc = upload(&L.W, w->desc_w[l], (size_t)L.nchunk * 9 * 16 * L.cout)) != BX_OK) return rc;
+        if ((rc = upload_w(L, w->desc_w[l])) != BX_OK) return rc;
         if ((rc = upload(&L.b, w->desc_b[l], (size_t)L.cout)) != BX_OK) return rc;
         if ((rc = upload_geo(L, cg)) != BX_OK) return rc;
     }
@@ -435,7 +451,7 @@ int bx_load_weights(bx_ctx* c, const bx_weights* w)
         ConvLayerDev& L = c->pose[l];
         L.nchunk = pc[l][0]; L.ntaps = k[0] * k[1] * k[2]; L.p_in = dims[0] * dims[1] * dims[2]; L.p_out = o[0] * o[1] * o[2];
         L.cout = pc[l][1]; L.relu = l < BX_NPOSE - 1;
-        if ((rc = upload(&L.W, w->pose_w[l], (size_t)L.nchunk * L.ntaps * 16 * L.cout)) != BX_OK) return rc;
+        if ((rc = upload_w(L, w->pose_w[l])) != BX_OK) return rc;
         if ((rc = upload(&L.b, w->pose_b[l], (size_t)L.cout)) != BX_OK) return rc;
         if ((rc = upload_geo(L, vg)) != BX_OK) return rc;
         for (int i = 0; i < 3; ++i) dims[i] = o[i];

@@ -159,15 +159,16 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
         bvs[j] = colok[j] ? bias[n0 + j * 16 + li] : 0.0f;
     }
 
-    const float* wbase = W + (size_t)kk * COUT + n0 + li;
+    // B fragments: device layout [chunk*tap][column tile][lane][4] (bx_load_weights) -> ONE 16-byte load per lane and tap
+    const float4* wbase = reinterpret_cast<const float4*>(W) + (size_t)(wn * NPW) * 64 + lane;
     auto loadB = [&](int ct, float (&b)[NPW][4]) {
-        const float* wp = wbase + (size_t)ct * 16 * COUT;
+#ifdef BX_EXP_NOB
+        if (ct != 0) return;
+#endif
 #pragma unroll
         for (int j = 0; j < NPW; ++j) {
-            b[j][0] = colok[j] ? wp[j * 16] : 0.f;
-            b[j][1] = colok[j] ? wp[j * 16 + 4 * COUT] : 0.f;
-            b[j][2] = colok[j] ? wp[j * 16 + 8 * COUT] : 0.f;
-            b[j][3] = colok[j] ? wp[j * 16 + 12 * COUT] : 0.f;
+            const float4 v = wbase[((size_t)ct * C::NT + j) * 64];
+            b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
         }
     };
     float bc[NPW][4], bn[NPW][4];
@@ -236,19 +237,28 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
                 loadB(ctn, bt[i]);
             }
             // next slab: the next chunk of this group, or chunk 0 of this workgroup's NEXT group (its prologue disappears)
+#ifndef BX_EXP_NOGLOAD
             if (cc + 1 < NCHUNK) gload(cc + 1, u0);
             else if (grp_next < ngroups) gload(0, grp_next * G);
+#endif
             do_tap(T0, bc);
 #pragma unroll
-            for (int i = 0; i < KT; ++i) do_tap(T0 + 1 + i, bt[i]);
+            for (int i = 0; i + 1 < KT; ++i) do_tap(T0 + 1 + i, bt[i]);
+            // hand the next slab to LDS BEFORE the last tap: the other buffer has been free since the previous barrier, so
+            // the LDS writes overlap the other waves' MFMAs and the barrier below only waits for the last tap
+#ifndef BX_EXP_NOGLOAD
+            if (cc + 1 < NCHUNK || grp_next < ngroups) lwrite((sl + 1) & 1);
+#endif
+            if (KT > 0) do_tap(T0 + KT, bt[KT > 0 ? KT - 1 : 0]);
 #pragma unroll
             for (int j = 0; j < NPW; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bc[j][i] = bt[KT][j][i];
         }
         CV_TR(2 + 2 * cc);
-        if (cc + 1 < NCHUNK || grp_next < ngroups) lwrite((sl + 1) & 1);
+#ifndef BX_EXP_NOGLOAD
         __syncthreads();
+#endif
         CV_TR(3 + 2 * cc);
     }
 
@@ -269,6 +279,9 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
                     for (int j = 0; j < NPW; ++j) {
                         float v = acc[t][j][r];
                         if (RELU) v = v > 0.0f ? v : 0.0f;
+#ifdef BX_EXP_NOSTORE
+                        if (v == 12345.678f)
+#endif
                         out[(((size_t)(u0 + g) * C::NT + wn * NPW + j) * P_OUT + pos) * 16 + slot] = v;
                     }
                 }
@@ -337,8 +350,8 @@ __global__ __launch_bounds__(CT) void cost_l1_kernel(const float* __restrict__ s
 #pragma unroll 1
         for (int tp = 0; tp < NTAPS; ++tp) {
             const int a = tp / 9, b = (tp / 3) % 3, c = tp % 3;
-            const float* wp = W + (((size_t)cc * NTAPS + tp) * 16 + kk) * COUT + n0 + li;
-            float b0 = wp[0], b1 = wp[4 * COUT], b2 = wp[8 * COUT], b3 = wp[12 * COUT];
+            const float4 bq = reinterpret_cast<const float4*>(W)[(((size_t)cc * NTAPS + tp) * (COUT / 16) + wn) * 64 + lane];
+            float b0 = bq.x, b1 = bq.y, b2 = bq.z, b3 = bq.w;
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 const int mt = wm + t * WM;
