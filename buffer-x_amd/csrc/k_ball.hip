@@ -258,6 +258,40 @@ struct F3 { float x, y, z; };   // 4-byte aligned triple: stores compile to glob
 constexpr int QU = 8;            // candidate loads in flight per lane
 constexpr int MAXROWS = 63;      // (y,z) cell rows kept in the per-wave row table (one lane each)
 
+// Row tables of all keypoints, one wave per keypoint: lane k < R gets {first sorted-array slot, candidate count} of
+// the k-th (y,z) cell row around the keypoint; lane 63 carries R (or -1: degenerate geometry, the query kernel walks the
+// cells itself).  Doing this in its own launch takes one dependent memory round trip out of every query workgroup.
+__global__ __launch_bounds__(256) void ball_rows_kernel(const int32_t* __restrict__ start, const BallGrid* __restrict__ g,
+                                                        const float* __restrict__ kpts, int K, int2* __restrict__ rowtab,
+                                                        const int32_t* __restrict__ skip)
+{
+    if (skip && *skip) return;
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= K) return;
+    const float qx = kpts[(size_t)q * 3], qy = kpts[(size_t)q * 3 + 1], qz = kpts[(size_t)q * 3 + 2];
+    const float ox = g->ox, oy = g->oy, oz = g->oz, ih = g->inv_h, rp = g->rpad;
+    const int dx = g->dx, dy = g->dy, dz = g->dz;
+    const int xlo = cell_coord(qx - rp, ox, ih, dx), xhi = cell_coord(qx + rp, ox, ih, dx);
+    const int ylo = cell_coord(qy - rp, oy, ih, dy), yhi = cell_coord(qy + rp, oy, ih, dy);
+    const int zlo = cell_coord(qz - rp, oz, ih, dz), zhi = cell_coord(qz + rp, oz, ih, dz);
+    const int ny = yhi - ylo + 1, nz = zhi - zlo + 1;
+    const int R = ny * nz;
+    int2 e = make_int2(0, 0);
+    if (R <= 63) {
+        if (lane < R) {
+            const int cz = zlo + lane / ny, cy = ylo + lane % ny;
+            const int rowc = (cz * dy + cy) * dx;
+            e.x = start[rowc + xlo];
+            e.y = start[rowc + xhi + 1] - e.x;
+        }
+        if (lane == 63) e = make_int2(R, 0);
+    } else if (lane == 63) {
+        e = make_int2(-1, 0);
+    }
+    rowtab[(size_t)q * 64 + lane] = e;
+}
+
 // QW waves per workgroup, ONE keypoint per workgroup (template parameter: 4 / 2 / 1 by the expected neighbourhood size)
 
 // Bit i of the hit bitmap: thread (i>>6) / CW owns CW = (1<<LOGC)/QW consecutive 64-bit words; its slot-th word sits at
@@ -278,7 +312,8 @@ __device__ __forceinline__ void set_hit(unsigned int* bm32, int i)
 // overwrites the bitmap once every thread holds its words in registers.
 template <int LOGC, int QW>
 __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __restrict__ sorted, const int32_t* __restrict__ start,
-                                                        const BallGrid* __restrict__ g, const float4* __restrict__ pts4,
+                                                        const BallGrid* __restrict__ g, const int2* __restrict__ rowtab,
+                                                        const float4* __restrict__ pts4,
                                                         const float* __restrict__ kpts, int K,
                                                         const double* __restrict__ radius, int P, int32_t* __restrict__ idx_out,
                                                         float* __restrict__ patches, const int32_t* __restrict__ skip,
@@ -303,31 +338,20 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
 #pragma unroll
     for (int s = 0; s < CW; ++s) bm64[s * QT + tid] = 0ULL;
 
+    const int2 rt = rowtab[(size_t)q * 64 + lane];          // prepared by ball_rows_kernel
     const float r = (float)(*radius);
     const float r2 = r * r;
     const float qx = kpts[(size_t)q * 3], qy = kpts[(size_t)q * 3 + 1], qz = kpts[(size_t)q * 3 + 2];
-    const float ox = g->ox, oy = g->oy, oz = g->oz, ih = g->inv_h, rp = g->rpad;
-    const int dx = g->dx, dy = g->dy, dz = g->dz;
-    const int xlo = cell_coord(qx - rp, ox, ih, dx), xhi = cell_coord(qx + rp, ox, ih, dx);
-    const int ylo = cell_coord(qy - rp, oy, ih, dy), yhi = cell_coord(qy + rp, oy, ih, dy);
-    const int zlo = cell_coord(qz - rp, oz, ih, dz), zhi = cell_coord(qz + rp, oz, ih, dz);
-    const int ny = yhi - ylo + 1, nz = zhi - zlo + 1;
-    const int R = ny * nz;
+    const int R = __builtin_amdgcn_readlane(rt.x, 63);     // -1: degenerate geometry
     BX_TR(1);
     __syncthreads();                                        // bitmap zeroed
 
-    if (R <= MAXROWS) {
+    if (R >= 0) {
         // ---- row table: every (y,z) row of cells is one contiguous range of the sorted array; the rows are laid end
         //      to end into ONE flat candidate sequence.  Lane k of every wave keeps row k's flat end offset (pe) and
         //      its sorted-array offset minus its flat start (rs); a 64-candidate chunk finds its rows with wave-uniform
-        //      readlanes (no LDS, no per-lane search).  The four waves take the 64*QU-candidate blocks round-robin.
-        int s_r = 0, len = 0;
-        if (lane < R) {
-            const int cz = zlo + lane / ny, cy = ylo + lane % ny;
-            const int rowc = (cz * dy + cy) * dx;
-            s_r = start[rowc + xlo];
-            len = start[rowc + xhi + 1] - s_r;
-        }
+        //      readlanes (no LDS, no per-lane search).  The waves take the 64*QU-candidate blocks round-robin.
+        const int s_r = lane < R ? rt.x : 0, len = lane < R ? rt.y : 0;
         const int inc = bx_wave_incl_scan_dpp(len);
         const int T = __builtin_amdgcn_readlane(inc, 63);
         const int rs = s_r - (inc - len);
@@ -365,6 +389,11 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
         }
     } else {
         // degenerate geometry (cell edge << radius because of the 1024-cells-per-axis floor): plain nested walk
+        const float ox = g->ox, oy = g->oy, oz = g->oz, ih = g->inv_h, rp = g->rpad;
+        const int dx = g->dx, dy = g->dy, dz = g->dz;
+        const int xlo = cell_coord(qx - rp, ox, ih, dx), xhi = cell_coord(qx + rp, ox, ih, dx);
+        const int ylo = cell_coord(qy - rp, oy, ih, dy), yhi = cell_coord(qy + rp, oy, ih, dy);
+        const int zlo = cell_coord(qz - rp, oz, ih, dz), zhi = cell_coord(qz + rp, oz, ih, dz);
         int rowi = 0;
         for (int cz = zlo; cz <= zhi; ++cz)
             for (int cy = ylo; cy <= yhi; ++cy, ++rowi) {
@@ -460,7 +489,7 @@ int launch_query_w(bx_ctx* c, hipStream_t s, int K, const float* kpts, const dou
         BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_kernel<LOGC, QW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         c->ball_attr_set |= 1 << (LOGC * 3 + QW / 2);
     }
-    hipLaunchKernelGGL((ball_query_kernel<LOGC, QW>), dim3(K), dim3(64 * QW), lds, s, c->ball_sorted, c->ball_start, c->ball_grid, c->ball_pts4, kpts, K,
+    hipLaunchKernelGGL((ball_query_kernel<LOGC, QW>), dim3(K), dim3(64 * QW), lds, s, c->ball_sorted, c->ball_start, c->ball_grid, c->ball_rowtab, c->ball_pts4, kpts, K,
                        radius, P, idx_out, patches_out, c->skip, getenv("BX_BALL_DEBUG") ? c->ball_dbg : nullptr);
     BX_LAUNCH_CHECK();
     return BX_OK;
@@ -520,6 +549,7 @@ int bxk_ball_group(bx_ctx* c, hipStream_t s, const float* pts_perm, int n, const
     hipLaunchKernelGGL(scan_sums_kernel, dim3(ntile), dim3(256), 0, s, c->ball_cnt, c->ball_grid, c->ball_bsum, skip);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(ntile), dim3(256), 0, s, c->ball_cnt, c->ball_grid, c->ball_bsum, c->ball_start, skip);
     hipLaunchKernelGGL(cell_scatter_kernel, dim3(nb), dim3(256), 0, s, c->ball_pts4, n, c->ball_cellrank, c->ball_start, c->ball_sorted, skip);
+    hipLaunchKernelGGL(ball_rows_kernel, dim3((K + 3) / 4), dim3(256), 0, s, c->ball_start, c->ball_grid, kpts, K, c->ball_rowtab, skip);
     bx_prof_mark(c, s, 12, 1);
     int rc = BX_OK;
     switch (logc) {
