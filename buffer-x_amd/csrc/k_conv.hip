@@ -44,7 +44,11 @@ struct ConvCfg {
     static constexpr int ROWS = G * P_LDS;
     static constexpr int BUF_FLOATS = ROWS * ROWF;
     static constexpr int NLD = (G * P_IN * 4 + CT - 1) / CT;
-    static constexpr size_t LDS_BYTES = (size_t)2 * BUF_FLOATS * 4;
+    static constexpr int EPI_FLOATS = 16 * ROWF;              // per-wave 16-row x 16-channel transposition scratch (epilogue)
+    // the scratch normally has its own LDS; the 972-row CostNet slab leaves no room, there it aliases the slab buffer
+    // that has just been consumed (and a barrier follows the epilogue)
+    static constexpr bool EPI_ALIAS = (size_t)2 * BUF_FLOATS * 4 + (size_t)NW * EPI_FLOATS * 4 > 160 * 1024;
+    static constexpr size_t LDS_BYTES = (size_t)2 * BUF_FLOATS * 4 + (EPI_ALIAS ? 0 : (size_t)NW * EPI_FLOATS * 4);
     // taps whose B fragments are all requested before the next slab's loads go out (see the tail of the tap loop)
     static constexpr int KT = NTAPS - 1 < 2 ? NTAPS - 1 : (TPW > 10 ? 1 : 2);
     // register budget: two co-resident workgroups (4 waves/SIMD, <= 128 VGPRs) when LDS allows two
@@ -262,31 +266,42 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
         CV_TR(3 + 2 * cc);
     }
 
-    // ---- epilogue of this group: ReLU, store in chunk-slot order (the next group's first slab is already in LDS)
-    int mrow0 = kk * 4;
-    asm volatile("" : "+v"(mrow0));   // keeps the 4*TPW store addresses out of the loop-invariant hoisting (VGPR budget)
+    // ---- epilogue of this group: ReLU, store in chunk-slot order (the next group's first slab is already in LDS).
+    //      A tile (16 rows x 16 channels) is 1 KiB contiguous in the output map; the accumulator layout (lane = channel,
+    //      4 rows per lane) is turned into row-major through a wave-private LDS scratch so that every lane issues ONE
+    //      16-byte store (the 4-byte scattered stores of the first version cost 3 % of the stack).
+    {
+        float* scr = (C::EPI_ALIAS ? buf + (size_t)((sl - 1) & 1) * C::BUF_FLOATS : buf + 2 * C::BUF_FLOATS) + wave * C::EPI_FLOATS;
+        int lrow16 = lane >> 2;
+        asm volatile("" : "+v"(lrow16));   // keeps the per-tile store addresses out of the loop-invariant hoisting (VGPR budget)
+        const int lpart = lane & 3;
 #pragma unroll
-    for (int t = 0; t < C::TPW; ++t) {
-        const int mt = wm + t * C::WM;
-        if (mt >= C::MT) continue;
+        for (int t = 0; t < C::TPW; ++t) {
+            const int mt = wm + t * C::WM;
+            if (mt >= C::MT) continue;
+            const int m = mt * 16 + lrow16;
+            const int g = m / P_OUT, pos = m - g * P_OUT;
+            const bool ok = m < C::M && u0 + g < units;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int m = mt * 16 + mrow0 + r;
-            if (m < C::M) {
-                int g = m / P_OUT, pos = m - g * P_OUT;
-                if (u0 + g < units) {
+            for (int j = 0; j < NPW; ++j) {
 #pragma unroll
-                    for (int j = 0; j < NPW; ++j) {
-                        float v = acc[t][j][r];
-                        if (RELU) v = v > 0.0f ? v : 0.0f;
-#ifdef BX_EXP_NOSTORE
-                        if (v == 12345.678f)
-#endif
-                        out[(((size_t)(u0 + g) * C::NT + wn * NPW + j) * P_OUT + pos) * 16 + slot] = v;
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[t][j][r];
+                    if (RELU) v = v > 0.0f ? v : 0.0f;
+                    scr[(kk * 4 + r) * ROWF + slot] = v;
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const float4 v4 = *reinterpret_cast<const float4*>(scr + lrow16 * ROWF + lpart * 4);
+                if (ok)
+                    *reinterpret_cast<float4*>(out + (((size_t)(u0 + g) * C::NT + wn * NPW + j) * P_OUT + pos) * 16 + lpart * 4) = v4;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         }
+        if (C::EPI_ALIAS) __syncthreads();
     }
     CV_TR(2 + 2 * NCHUNK);
     grp = grp_next;
