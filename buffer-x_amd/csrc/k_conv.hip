@@ -99,40 +99,40 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
     // ---- staging geometry of this thread's float4 pieces (constant over the chunks)
     const float4* in4 = reinterpret_cast<const float4*>(in);
     float4 st[C::NLD];
-    // (the piece geometry is recomputed per chunk from an opaque copy of tid: keeping 3*NLD hoisted address registers
-    //  alive across the MFMA loop costs the second co-resident workgroup on the 18-tile configurations)
-    auto piece = [&](int tq, int q, int ub, int& src, int& dst1, int& dst2) {
-        const int f = tq + q * CT;
+    // piece geometry (LDS destinations, source row) is fixed for the whole kernel: keep it in registers -- recomputing it
+    // per chunk put two dependent table loads in front of every LDS hand-off
+    int dst1[C::NLD], dst2[C::NLD];
+#pragma unroll
+    for (int q = 0; q < C::NLD; ++q) {
+        const int f = tid + q * CT;
         const int row = f >> 2, part = f & 3;
         const int g = row / P_IN, p = row - g * P_IN;
-        src = -1; dst1 = -1; dst2 = -1;
+        dst1[q] = -1; dst2[q] = -1;
         if (row < G * P_IN) {
-            dst1 = (g * P_LDS + lrow[p]) * ROWF + part * 4;
+            dst1[q] = (g * P_LDS + lrow[p]) * ROWF + part * 4;
             const int r2 = lrow2[p];
-            if (r2 >= 0) dst2 = (g * P_LDS + r2) * ROWF + part * 4;
-            if (ub + g < units) src = ((ub + g) * NCHUNK * P_IN + p) * 4 + part;   // float4 index of chunk 0 (< 2^31 at these sizes)
+            if (r2 >= 0) dst2[q] = (g * P_LDS + r2) * ROWF + part * 4;
         }
-    };
+    }
     auto gload = [&](int cc, int ub) {
         int tq = tid;
-        asm volatile("" : "+v"(tq));
+        asm volatile("" : "+v"(tq));      // source addresses are recomputed (pure integer math, no table loads): fewer live registers
 #pragma unroll
         for (int q = 0; q < C::NLD; ++q) {
-            int src, d1, d2;
-            piece(tq, q, ub, src, d1, d2);
-            st[q] = src >= 0 ? in4[(size_t)src + (size_t)cc * P_IN * 4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int f = tq + q * CT;
+            const int row = f >> 2, part = f & 3;
+            const int g = row / P_IN, p = row - g * P_IN;
+            st[q] = (row < G * P_IN && ub + g < units)
+                        ? in4[((size_t)(ub + g) * NCHUNK + cc) * P_IN * 4 + (size_t)p * 4 + part]
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto lwrite = [&](int b) {
         float* d = buf + (size_t)b * C::BUF_FLOATS;
-        int tq = tid;
-        asm volatile("" : "+v"(tq));
 #pragma unroll
         for (int q = 0; q < C::NLD; ++q) {
-            int src, d1, d2;
-            piece(tq, q, 0, src, d1, d2);
-            if (d1 >= 0) *reinterpret_cast<float4*>(d + d1) = st[q];
-            if (d2 >= 0) *reinterpret_cast<float4*>(d + d2) = st[q];
+            if (dst1[q] >= 0) *reinterpret_cast<float4*>(d + dst1[q]) = st[q];
+            if (dst2[q] >= 0) *reinterpret_cast<float4*>(d + dst2[q]) = st[q];
         }
     };
 
