@@ -58,6 +58,9 @@ struct ConvCfg {
     static constexpr int WPS_WANT = WG_LDS * NW / 4;                       // waves per SIMD the LDS would admit
     static constexpr int WPS_CAP = TPW * NPW <= 5 ? 6 : (TPW * NPW <= 10 ? (NW == 4 ? 5 : 4) : 2);
     static constexpr int MINW = WPS_WANT < WPS_CAP ? (WPS_WANT < 1 ? 1 : WPS_WANT) : WPS_CAP;
+    // cylindrical 3x3 layers: tap offsets are compile-time constants -> the tap loop is unrolled and the offset rides in the
+    // ds_read's immediate field (no address add per tile)
+    static constexpr bool CYLG = NTAPS == 9 && P_IN == BX_EA && P_LDS == (BX_ELE + 2) * (BX_AZI + 2);
     static_assert(NT % NPW == 0 && WN <= NW && NW % WN == 0, "waves must tile the output channels");
     static_assert(LDS_BYTES <= 160 * 1024, "slab double buffer exceeds the LDS");
     static_assert(NTAPS <= 64, "tap offsets live in one lane each");
@@ -198,15 +201,19 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
     for (int cc = 0; cc < NCHUNK; ++cc, ++sl) {
         const char* lb = reinterpret_cast<const char*>(buf + (size_t)(sl & 1) * C::BUF_FLOATS);
         // one tap: per tile ONE address add + ONE ds_read_b128 (issued two tiles ahead) + 4 back-to-back MFMAs
+        // per-chunk tile base = slab buffer + window origin; a tap adds a constant (immediate field of the ds_read when the
+        // geometry is compile-time, one v_add otherwise)
+        const char* ab[C::TPW];
+#pragma unroll
+        for (int t = 0; t < C::TPW; ++t) ab[t] = lb + abase[t];
         auto do_tap = [&](int tp, const float (&b_)[NPW][4]) {
-            const int tb = __builtin_amdgcn_readlane(toffv, tp);
-            const char* lt = lb + tb;
+            const int tb = C::CYLG ? ((tp / 3) * (BX_AZI + 2) + tp % 3) * (ROWF * 4) : __builtin_amdgcn_readlane(toffv, tp);
             f32x4 a[C::TPW];
-            a[0] = *reinterpret_cast<const f32x4*>(lt + abase[0]);
-            if (C::TPW > 1) a[C::TPW > 1 ? 1 : 0] = *reinterpret_cast<const f32x4*>(lt + abase[C::TPW > 1 ? 1 : 0]);
+            a[0] = *reinterpret_cast<const f32x4*>(ab[0] + tb);
+            if (C::TPW > 1) a[C::TPW > 1 ? 1 : 0] = *reinterpret_cast<const f32x4*>(ab[C::TPW > 1 ? 1 : 0] + tb);
 #pragma unroll
             for (int t = 0; t < C::TPW; ++t) {
-                if (t + 2 < C::TPW) a[t + 2 < C::TPW ? t + 2 : 0] = *reinterpret_cast<const f32x4*>(lt + abase[t + 2 < C::TPW ? t + 2 : 0]);
+                if (t + 2 < C::TPW) a[t + 2 < C::TPW ? t + 2 : 0] = *reinterpret_cast<const f32x4*>(ab[t + 2 < C::TPW ? t + 2 : 0] + tb);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < NPW; ++j) {
@@ -220,14 +227,26 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
         };
         // head taps [0, T0): the B fragment of the next tap is fetched while the current one is on the matrix cores
         constexpr int KT = C::KT, T0 = NTAPS - 1 - KT;
+        if constexpr (C::CYLG) {
+#pragma unroll
+            for (int tp = 0; tp < T0; ++tp) {
+                loadB(cc * NTAPS + tp + 1, bn);
+                do_tap(tp, bc);
+#pragma unroll
+                for (int j = 0; j < NPW; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bc[j][i] = bn[j][i];
+            }
+        } else {
 #pragma unroll 1
-        for (int tp = 0; tp < T0; ++tp) {
-            loadB(cc * NTAPS + tp + 1, bn);
-            do_tap(tp, bc);
+            for (int tp = 0; tp < T0; ++tp) {
+                loadB(cc * NTAPS + tp + 1, bn);
+                do_tap(tp, bc);
 #pragma unroll
-            for (int j = 0; j < NPW; ++j)
+                for (int j = 0; j < NPW; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) bc[j][i] = bn[j][i];
+                    for (int i = 0; i < 4; ++i) bc[j][i] = bn[j][i];
+            }
         }
         // tail taps [T0, NTAPS): vmcnt retires IN ORDER, so a B fetch issued after the slab load would wait for the
         // slab's HBM round trip.  Every remaining B fragment of this chunk AND the first one of the next chunk are
