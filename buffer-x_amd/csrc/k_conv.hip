@@ -337,74 +337,106 @@ constexpr int CV_POUT = CV_DO * CV_HO * CV_WO;                        // 972
 constexpr int CT = 512;                                              // threads of the cost-volume kernel
 constexpr int CV_ROWF = 36;                                           // 32 + 4 pad floats per LDS row
 
-__global__ __launch_bounds__(CT) void cost_l1_kernel(const float* __restrict__ s_equi, const float* __restrict__ t_equi,
-                                                     const int32_t* __restrict__ s_mids, const int32_t* __restrict__ t_mids,
-                                                     const int32_t* __restrict__ m_dev, int max_m, const float* __restrict__ W,
-                                                     const float* __restrict__ bias, float* __restrict__ out, const int32_t* __restrict__ skip)
+// One workgroup per match.  S (source equivariant map, elevation rows 1..5) is staged with a +-2 column wrap-around
+// halo ([5][24] rows) and T as [5][20] rows, both channels-last in chunk-slot order.  With e = (l - n) mod 20 per output
+// row, the A operand of tap (a,b,c) is  S_ext[k+b][e + 2 + c - a] - T[k+b][l+c]:  "row base + constant", so each tile
+// costs two ds_read_b128 (immediate offsets), four v_sub and -- a wave owns both 16-channel column tiles -- EIGHT MFMAs.
+constexpr int CV_WE = CV_W + 4;                                       // 24 columns of the wrapped S map
+
+__global__ __launch_bounds__(CT, 3) void cost_l1_kernel(const float* __restrict__ s_equi, const float* __restrict__ t_equi,
+                                                        const int32_t* __restrict__ s_mids, const int32_t* __restrict__ t_mids,
+                                                        const int32_t* __restrict__ m_dev, int max_m, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, float* __restrict__ out, const int32_t* __restrict__ skip)
 {
     if (skip && *skip) return;
     constexpr int MT = (CV_POUT + 15) / 16;  // 61
-    constexpr int WN = 2, WM = 4, TPW = (MT + WM - 1) / WM;
-    constexpr int NTAPS = 27, COUT = 32;
-    __shared__ __attribute__((aligned(16))) float sS[CV_H * CV_W * CV_ROWF];
+    constexpr int WM = 8, TPW = (MT + WM - 1) / WM;   // 8 row tiles per wave, both column tiles
+    constexpr int NTAPS = 27;
+    constexpr int ROWB = CV_ROWF * 4;                 // bytes per LDS row (32 channels + pad)
+    __shared__ __attribute__((aligned(16))) float sS[CV_H * CV_WE * CV_ROWF];
     __shared__ __attribute__((aligned(16))) float sT[CV_H * CV_W * CV_ROWF];
 
     int m = *m_dev;
     m = m < max_m ? m : max_m;
     const int u = blockIdx.x;
     if (u >= m) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave % WN, wm = wave / WN;
+    const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
     const int li = lane & 15, kk = lane >> 4;
 
     const float* sp = s_equi + ((size_t)s_mids[u] * BX_EA + BX_AZI) * 32;  // elevation rows 1..5
     const float* tp_ = t_equi + ((size_t)t_mids[u] * BX_EA + BX_AZI) * 32;
     for (int f = tid; f < CV_H * CV_W * 32; f += CT) {
-        int row = f >> 5, c = f & 31;
-        int sl = (c & 16) + 4 * (c & 3) + ((c & 15) >> 2);
-        sS[row * CV_ROWF + sl] = sp[f];
+        const int row = f >> 5, c = f & 31;
+        const int k = row / CV_W, l = row - k * CV_W;
+        const int sl = (c & 16) + 4 * (c & 3) + ((c & 15) >> 2);
+        const float sv = sp[f];
+        sS[(k * CV_WE + l + 2) * CV_ROWF + sl] = sv;
+        if (l >= CV_W - 2) sS[(k * CV_WE + l + 2 - CV_W) * CV_ROWF + sl] = sv;      // columns -2, -1
+        if (l < 2) sS[(k * CV_WE + l + 2 + CV_W) * CV_ROWF + sl] = sv;              // columns 20, 21
         sT[row * CV_ROWF + sl] = tp_[f];
     }
     __syncthreads();
 
-    const int n0 = wn * 16;
-    const float bv = bias[n0 + li];
-    f32x4 acc[TPW];
-    int nkl[TPW];
+    f32x4 acc[TPW][2];
+    int bS[TPW], bT[TPW];
+    {
+        const float bv0 = bias[li], bv1 = bias[16 + li];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        acc[t] = (f32x4){bv, bv, bv, bv};
-        int mrow = (wm + t * WM) * 16 + li;
-        if (mrow >= CV_POUT) mrow = CV_POUT - 1;
-        int n = mrow / (CV_HO * CV_WO), rem = mrow - n * (CV_HO * CV_WO);
-        int k = rem / CV_WO, l = rem - k * CV_WO;
-        nkl[t] = (n << 16) | (k << 8) | l;
+        for (int t = 0; t < TPW; ++t) {
+            acc[t][0] = (f32x4){bv0, bv0, bv0, bv0};
+            acc[t][1] = (f32x4){bv1, bv1, bv1, bv1};
+            int mrow = (wm + t * WM) * 16 + li;
+            if (mrow >= CV_POUT) mrow = CV_POUT - 1;
+            const int n = mrow / (CV_HO * CV_WO), rem = mrow - n * (CV_HO * CV_WO);
+            const int k = rem / CV_WO, l = rem - k * CV_WO;
+            int e = l - n;
+            e = e < 0 ? e + CV_W : e;
+            bS[t] = ((k * CV_WE + e + 2) * CV_ROWF + kk * 4) * 4;
+            bT[t] = ((k * CV_W + l) * CV_ROWF + kk * 4) * 4;
+        }
     }
+    const char* cS = reinterpret_cast<const char*>(sS);
+    const char* cT = reinterpret_cast<const char*>(sT);
+    const float4* w4 = reinterpret_cast<const float4*>(W) + lane;
+    float4 bq0 = w4[0], bq1 = w4[64];
+#pragma unroll 1
     for (int cc = 0; cc < 2; ++cc) {
 #pragma unroll 1
-        for (int tp = 0; tp < NTAPS; ++tp) {
-            const int a = tp / 9, b = (tp / 3) % 3, c = tp % 3;
-            const float4 bq = reinterpret_cast<const float4*>(W)[(((size_t)cc * NTAPS + tp) * (COUT / 16) + wn) * 64 + lane];
-            float b0 = bq.x, b1 = bq.y, b2 = bq.z, b3 = bq.w;
+        for (int a = 0; a < 3; ++a) {
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                const int mt = wm + t * WM;
-                if (mt < MT) {
-                    int n = nkl[t] >> 16, k = (nkl[t] >> 8) & 255, l = nkl[t] & 255;
-                    int tc = l + c;
-                    int sc = tc - (n + a);
-                    sc = sc < 0 ? sc + CV_W : sc;
-                    int rbase = (k + b) * CV_W;
-                    f32x4 sv = *reinterpret_cast<const f32x4*>(sS + (size_t)(rbase + sc) * CV_ROWF + cc * 16 + kk * 4);
-                    f32x4 tv = *reinterpret_cast<const f32x4*>(sT + (size_t)(rbase + tc) * CV_ROWF + cc * 16 + kk * 4);
-                    f32x4 av = sv - tv;
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b1, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b2, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b3, acc[t], 0, 0, 0);
+            for (int bc = 0; bc < 9; ++bc) {
+                const int b = bc / 3, c = bc % 3;
+                const int tp = a * 9 + bc;
+                // B fragments of the next tap (wraps harmlessly after the last one)
+                int nx = cc * NTAPS + tp + 1;
+                nx = nx < 2 * NTAPS ? nx : 0;
+                const float4 nq0 = w4[(size_t)nx * 128], nq1 = w4[(size_t)nx * 128 + 64];
+                const int offS = (b * CV_WE + c) * ROWB + cc * 64;
+                const int offT = (b * CV_W + c) * ROWB + cc * 64;
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    const f32x4 sv = *reinterpret_cast<const f32x4*>(cS + bS[t] + offS);
+                    const f32x4 tv = *reinterpret_cast<const f32x4*>(cT + bT[t] + offT);
+                    const f32x4 av = sv - tv;
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bq0.x, acc[t][0], 0, 0, 0);
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bq0.y, acc[t][0], 0, 0, 0);
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bq0.z, acc[t][0], 0, 0, 0);
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bq0.w, acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bq1.x, acc[t][1], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bq1.y, acc[t][1], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bq1.z, acc[t][1], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bq1.w, acc[t][1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                bq0 = nq0; bq1 = nq1;
             }
+            // next a: the S column moves one to the left
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) bS[t] -= ROWB;
         }
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) bS[t] += 3 * ROWB;
     }
     const int slot = 4 * (li & 3) + (li >> 2);
 #pragma unroll
@@ -413,11 +445,14 @@ __global__ __launch_bounds__(CT) void cost_l1_kernel(const float* __restrict__ s
         if (mt >= MT) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            int mrow = mt * 16 + kk * 4 + r;
+            const int mrow = mt * 16 + kk * 4 + r;
             if (mrow < CV_POUT) {
-                float v = acc[t][r];
-                v = v > 0.0f ? v : 0.0f;
-                out[(((size_t)u * 2 + wn) * CV_POUT + mrow) * 16 + slot] = v;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float v = acc[t][j][r];
+                    v = v > 0.0f ? v : 0.0f;
+                    out[(((size_t)u * 2 + j) * CV_POUT + mrow) * 16 + slot] = v;
+                }
             }
         }
     }
