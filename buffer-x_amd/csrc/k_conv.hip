@@ -180,10 +180,13 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
     };
     float bc[NPW][4], bn[NPW][4];
     loadB(0, bc);
+    if constexpr (C::CYLG) loadB(1, bn);
+    else {
 #pragma unroll
-    for (int j = 0; j < NPW; ++j)
+        for (int j = 0; j < NPW; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bn[j][i] = 0.f;
+            for (int i = 0; i < 4; ++i) bn[j][i] = 0.f;
+    }
     // drain the prologue loads here: otherwise the waitcnt pass sees them pending on the loop's entry edge and
     // waits for the NEWEST loads (the counters are in-order) in front of every tap's first MFMAs
     __builtin_amdgcn_s_waitcnt(0);
@@ -225,28 +228,50 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
+        if constexpr (C::CYLG) {
+            // Unrolled 9-tap schedule, B fragments requested TWO taps ahead (one tap of MFMAs is not always longer than an
+            // L2 round trip under load); the fragments of the next chunk's taps 0 and 1 and then the next slab go out at
+            // tap 6, so nothing issued after the slab load is waited for before the LDS hand-off (vmcnt retires in order).
+            float b2[NPW][4], b3[NPW][4], b4[NPW][4], b5[NPW][4], b6[NPW][4], b7[NPW][4], b8[NPW][4], n0b[NPW][4], n1b[NPW][4];
+            const int cb = cc * NTAPS;
+            loadB(cb + 2, b2); do_tap(0, bc);
+            loadB(cb + 3, b3); do_tap(1, bn);
+            loadB(cb + 4, b4); do_tap(2, b2);
+            loadB(cb + 5, b5); do_tap(3, b3);
+            loadB(cb + 6, b6); do_tap(4, b4);
+            loadB(cb + 7, b7); do_tap(5, b5);
+            loadB(cb + 8, b8);
+            {
+                int c0 = cb + 9, c1 = cb + 10;
+                if (c0 >= NCHUNK * NTAPS) c0 -= NCHUNK * NTAPS;       // first taps of the next group's chunk 0
+                if (c1 >= NCHUNK * NTAPS) c1 -= NCHUNK * NTAPS;
+                loadB(c0, n0b); loadB(c1, n1b);
+            }
+#ifndef BX_EXP_NOGLOAD
+            if (cc + 1 < NCHUNK) gload(cc + 1, u0);
+            else if (grp_next < ngroups) gload(0, grp_next * G);
+#endif
+            do_tap(6, b6);
+            do_tap(7, b7);
+#ifndef BX_EXP_NOGLOAD
+            if (cc + 1 < NCHUNK || grp_next < ngroups) lwrite((sl + 1) & 1);
+#endif
+            do_tap(8, b8);
+#pragma unroll
+            for (int j = 0; j < NPW; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { bc[j][i] = n0b[j][i]; bn[j][i] = n1b[j][i]; }
+        } else {
         // head taps [0, T0): the B fragment of the next tap is fetched while the current one is on the matrix cores
         constexpr int KT = C::KT, T0 = NTAPS - 1 - KT;
-        if constexpr (C::CYLG) {
-#pragma unroll
-            for (int tp = 0; tp < T0; ++tp) {
-                loadB(cc * NTAPS + tp + 1, bn);
-                do_tap(tp, bc);
-#pragma unroll
-                for (int j = 0; j < NPW; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) bc[j][i] = bn[j][i];
-            }
-        } else {
 #pragma unroll 1
-            for (int tp = 0; tp < T0; ++tp) {
-                loadB(cc * NTAPS + tp + 1, bn);
-                do_tap(tp, bc);
+        for (int tp = 0; tp < T0; ++tp) {
+            loadB(cc * NTAPS + tp + 1, bn);
+            do_tap(tp, bc);
 #pragma unroll
-                for (int j = 0; j < NPW; ++j)
+            for (int j = 0; j < NPW; ++j)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) bc[j][i] = bn[j][i];
-            }
+                for (int i = 0; i < 4; ++i) bc[j][i] = bn[j][i];
         }
         // tail taps [T0, NTAPS): vmcnt retires IN ORDER, so a B fetch issued after the slab load would wait for the
         // slab's HBM round trip.  Every remaining B fragment of this chunk AND the first one of the next chunk are
@@ -277,6 +302,7 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
             for (int j = 0; j < NPW; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bc[j][i] = bt[KT][j][i];
+        }
         }
         CV_TR(2 + 2 * cc);
 #ifndef BX_EXP_NOGLOAD
