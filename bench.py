@@ -60,7 +60,7 @@ def make_inputs(bx, oracle_perm, n_pairs, base_seed, S):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--inflight", type=int, default=3, help="pairs in flight per GPU (contexts / HIP streams)")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs per rank (cycled)")
