@@ -46,6 +46,41 @@ struct Rec {
     float x, y, z;
 };
 
+// max over the 64 lanes on the DPP network (result valid in lane 63, returned broadcast through v_readlane)
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+    const int id = (int)0x80000000;
+    int o;
+    o = __builtin_amdgcn_update_dpp(id, v, 0x111, 0xf, 0xf, false); v = o > v ? o : v;   // row_shr:1
+    o = __builtin_amdgcn_update_dpp(id, v, 0x112, 0xf, 0xf, false); v = o > v ? o : v;   // row_shr:2
+    o = __builtin_amdgcn_update_dpp(id, v, 0x114, 0xf, 0xf, false); v = o > v ? o : v;   // row_shr:4
+    o = __builtin_amdgcn_update_dpp(id, v, 0x118, 0xf, 0xf, false); v = o > v ? o : v;   // row_shr:8
+    o = __builtin_amdgcn_update_dpp(id, v, 0x142, 0xa, 0xf, false); v = o > v ? o : v;   // row_bcast:15
+    o = __builtin_amdgcn_update_dpp(id, v, 0x143, 0xc, 0xf, false); v = o > v ? o : v;   // row_bcast:31
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+    unsigned o;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); v = o > v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); v = o > v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); v = o > v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); v = o > v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); v = o > v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); v = o > v ? o : v;
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// 64-bit key max as two 32-bit DPP reductions: high word (signed: fp32 bits of the distance, -1.0f = "no candidate"),
+// then the low word (unsigned) among the lanes that hold the maximal high word
+__device__ __forceinline__ long long wave_max_key(long long key)
+{
+    const int hi = (int)(key >> 32);
+    const unsigned lo = (unsigned)((unsigned long long)key & 0xffffffffu);
+    const int mh = wave_max_i32(hi);
+    const unsigned ml = wave_max_u32(hi == mh ? lo : 0u);
+    return (long long)(((unsigned long long)(unsigned)mh << 32) | ml);
+}
+
 template <int PPT>
 __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
 {
@@ -109,13 +144,8 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
         unsigned k = (unsigned)(base + bi * FPS_THREADS + t);
         unsigned tb = ((k & tmask) << 23) | (k >> lt);
         long long key = ((long long)__float_as_int(bd) << 32) | (long long)(unsigned)(~tb);
-        // wave max (signed 64-bit)
-        long long wk = key;
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) {
-            long long o = __shfl_xor(wk, s, 64);
-            wk = o > wk ? o : wk;
-        }
+        // wave max (signed 64-bit) on the DPP network
+        const long long wk = wave_max_key(key);
         if (key == wk) {  // keys are unique per thread (they embed the point index)
             s_key[par][wave] = wk;
             s_xyz[par][wave][0] = bx; s_xyz[par][wave][1] = by; s_xyz[par][wave][2] = bz;
@@ -138,13 +168,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
             if (wave == 0) {
                 // combine the 16 wave records
                 long long k0 = lane < FPS_WAVES ? s_key[par][lane] : (long long)0x8000000000000000LL;
-                long long mk = k0;
-#pragma unroll
-                for (int s = 8; s >= 1; s >>= 1) {
-                    long long o = __shfl_xor(mk, s, 64);
-                    mk = o > mk ? o : mk;
-                }
-                mk = __shfl(mk, 0, 64);
+                const long long mk = wave_max_key(k0);
                 // the (unique, or lowest) lane holding the max publishes this workgroup's record
                 unsigned long long bal = __ballot(lane < FPS_WAVES && k0 == mk);
                 int src = __ffsll((long long)bal) - 1;
@@ -184,13 +208,14 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                 // gather record w: granules 5w..5w+4 -> lanes; reduce
                 long long bestk = (long long)0x8000000000000000LL;
                 float ox = 0.f, oy = 0.f, oz = 0.f;
+                auto granule = [&](int qq) -> unsigned {    // wave-uniform index: v_readlane, no LDS crossbar
+                    return qq < 64 ? (unsigned)__builtin_amdgcn_readlane((int)val[0], qq)
+                                   : (unsigned)__builtin_amdgcn_readlane((int)val[1], qq - 64);
+                };
                 for (int w = 0; w < G; ++w) {
-                    int q0 = 5 * w;
-                    unsigned hi = __shfl(q0 < 64 ? val[0] : val[1], q0 & 63, 64);
-                    unsigned lo = __shfl((q0 + 1) < 64 ? val[0] : val[1], (q0 + 1) & 63, 64);
-                    unsigned ux = __shfl((q0 + 2) < 64 ? val[0] : val[1], (q0 + 2) & 63, 64);
-                    unsigned uy = __shfl((q0 + 3) < 64 ? val[0] : val[1], (q0 + 3) & 63, 64);
-                    unsigned uz = __shfl((q0 + 4) < 64 ? val[0] : val[1], (q0 + 4) & 63, 64);
+                    const int q0 = 5 * w;
+                    const unsigned hi = granule(q0), lo = granule(q0 + 1);
+                    const unsigned ux = granule(q0 + 2), uy = granule(q0 + 3), uz = granule(q0 + 4);
                     long long kk = (long long)(((unsigned long long)hi << 32) | lo);
                     if (kk > bestk) { bestk = kk; ox = __uint_as_float(ux); oy = __uint_as_float(uy); oz = __uint_as_float(uz); }
                 }
