@@ -149,3 +149,22 @@ def test_full_size_properties(bx, packed, oracle):
     inc = np.diff(nidx.astype(np.int64), axis=1)
     assert np.all((inc > 0) | ~real[:, 1:] | ~real[:, :-1] | (np.arange(1, P)[None, :] == P - 1))
     ctx.close()
+
+
+def test_pair_tiny_clouds(bx, packed, oracle):
+    """Clouds smaller than num_fps and than num_points_per_patch (a cropped fragment): the whole path must stay
+    well-defined and identical to the oracle (duplicate keypoints, padded patches, few or no mutual matches)."""
+    from oracle import pipeline as PL
+    cfg = bx.make_cfg("3DMatch")
+    cfg.patch.num_fps, cfg.patch.num_points_per_patch, cfg.patch.num_scales = 128, 96, 2
+    cfg.patch.search_radius_thresholds = [5, 2]
+    cfg.patch.num_points_radius_estimate = 128
+    cfg.match.iter_n = 500
+    pair = bx.synth.make_pair(8, "indoor", n_target=3000)
+    rng = np.random.default_rng(0)
+    pair["src"] = np.ascontiguousarray(pair["src"][rng.choice(len(pair["src"]), 90, replace=False)])
+    pair["tgt"] = np.ascontiguousarray(pair["tgt"][rng.choice(len(pair["tgt"]), 70, replace=False)])
+    pose, n_inl, n_mut, n_ind, scales, _ = run_gpu(bx, packed, oracle, cfg, pair, 2)
+    ref = PL.register_pair(pair["src"], pair["tgt"], packed, cfg, pair["aligned_z"], 2)
+    assert (n_inl, n_mut, n_ind, scales) == tuple(ref[1:])
+    assert np.array_equal(pose, np.asarray(ref[0], np.float64))

@@ -349,3 +349,26 @@ def test_ransac_degenerate(bx, packed, oracle):
     T, info = c.ransac(s, s, np.arange(2, dtype=np.int32), torch.tensor([2], dtype=torch.int32), 64, 1)
     assert np.array_equal(_np(T).reshape(4, 4), np.eye(4)) and _np(info)[0] == 0   # C < 3 -> identity, 0 inliers
     c.close()
+
+
+# ------------------------------------------------------------------ degenerate sizes
+def test_fps_more_samples_than_points(ctx, oracle):
+    """m > n: once every point has been selected all running distances are 0 and the tie rule decides (upstream keeps
+    sampling); the GPU must replay exactly the oracle's sequence."""
+    rng = np.random.default_rng(3)
+    xyz = (rng.random((150, 3), np.float32) * 2 + 0.5).astype(np.float32)
+    idx, kp = ctx.fps(xyz, 256)
+    ref = oracle.fps(xyz, 256)
+    assert np.array_equal(_np(idx), ref)
+    assert np.array_equal(_np(kp), xyz[ref])
+
+
+def test_ball_group_patch_larger_than_cloud(ctx, oracle):
+    """P > n: every keypoint has fewer than P neighbours; padding and the keypoint slot must follow the reference rule."""
+    import torch
+    rng = np.random.default_rng(4)
+    pts = rng.random((90, 3), np.float32)
+    kp = pts[:12].copy()
+    idx, patches = ctx.ball_group(pts, kp, torch.tensor([0.6], dtype=torch.float64), 128)
+    ridx, rp = oracle.ball_group(pts, kp, np.float32(0.6), 128)
+    assert np.array_equal(_np(idx), ridx) and np.array_equal(_np(patches), rp)
