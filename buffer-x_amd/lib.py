@@ -59,6 +59,9 @@ def load():
     """Load the HIP library; raises (never falls back) when it is missing."""
     global _LIB
     if _LIB is None:
+        # torch first: it ships its own HIP runtime; if /opt/rocm's copy were loaded before it (this library links
+        # against libamdhip64), the two runtimes would disagree about the devices ("no ROCm-capable device")
+        import torch  # noqa: F401
         if not os.path.exists(_SO):
             raise RuntimeError(f"{_SO} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(the HIP path has no CPU fallback)")
