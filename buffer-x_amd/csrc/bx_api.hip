@@ -354,6 +354,7 @@ int bx_destroy(bx_ctx* c)
     if (!c) return BX_OK;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
+    bxk_pre_release(c);
     (void)hipFree(c->arena);
     (void)hipFree(c->d_centres); (void)hipFree(c->d_rot); (void)hipFree(c->d_rowc); (void)hipFree(c->d_rad_thr);
     (void)hipFree(c->d_pnt_w); (void)hipFree(c->d_pnt_b); (void)hipFree(c->d_pool_w1); (void)hipFree(c->d_pool_b1); (void)hipFree(c->d_pool_w2); (void)hipFree(c->d_pool_b2);
@@ -587,6 +588,31 @@ int bx_refine(bx_ctx* c, void* stream, const float* ss, const float* tt, const i
     if ((rc = check_ctx(c, false)) != BX_OK) return rc;
     if (max_M > c->p.num_fps * c->p.num_scales) { bx_set_error("bx_refine: max_M exceeds num_fps*num_scales"); return BX_ERR_ARG; }
     return bxk_refine(c, (hipStream_t)stream, ss, tt, M_dev, max_M, T_io, iters_out);
+}
+
+// ------------------------------------------------------------------------------------------------ pre-processing
+int bx_pre_reserve(bx_ctx* c, int64_t max_points)
+{
+    int rc;
+    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    BX_HIP(hipSetDevice(c->device));
+    return bxk_pre_reserve(c, max_points);
+}
+
+int bx_pre_voxel_downsample(bx_ctx* c, void* stream, const float* pts, int32_t n, double voxel_size, float* out, int32_t* count_out)
+{
+    int rc;
+    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    if (!pts || !out || !count_out) { bx_set_error("bx_pre_voxel_downsample: null argument"); return BX_ERR_ARG; }
+    return bxk_pre_voxel_downsample(c, (hipStream_t)stream, pts, n, voxel_size, out, count_out);
+}
+
+int bx_pre_pca(bx_ctx* c, void* stream, const float* pts, int32_t n, const int32_t* sample_idx, int32_t ns, double* out17)
+{
+    int rc;
+    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    if (!pts || !sample_idx || !out17) { bx_set_error("bx_pre_pca: null argument"); return BX_ERR_ARG; }
+    return bxk_pre_pca(c, (hipStream_t)stream, pts, n, sample_idx, ns, out17);
 }
 
 // ------------------------------------------------------------------------------------------------ whole pair

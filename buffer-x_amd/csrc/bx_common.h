@@ -129,6 +129,7 @@ struct bx_ctx {
     bx_result* result_dev;              // device staging of the result
     int32_t* err_flag;                  // device error flag
     const int32_t* skip;                // device flag: non-zero => pipeline kernels return immediately (early exit)
+    void* pre;                          // bx_pre_ws* (k_pre.hip): workspace of the pre-processing entry points, reserved on demand
     int prof_on;
     void* prof;                         // std::vector<ProfEvt>* (bx_api.hip)
 };
@@ -161,6 +162,10 @@ int bxk_consensus(bx_ctx* c, hipStream_t s, const float* R, const float* t, cons
                   const int32_t* M_dev, int max_M, int32_t* inlier_out, int32_t* count_out, int32_t* best_out);
 int bxk_ransac(bx_ctx* c, hipStream_t s, const float* ss, const float* tt, const int32_t* corr, const int32_t* C_dev,
                int max_C, uint64_t seed, double* T_out, int32_t* info_out, const int32_t* skip_flag);
+int bxk_pre_reserve(bx_ctx* c, int64_t max_points);
+void bxk_pre_release(bx_ctx* c);
+int bxk_pre_voxel_downsample(bx_ctx* c, hipStream_t s, const float* pts, int n, double voxel_size, float* out, int32_t* count_out);
+int bxk_pre_pca(bx_ctx* c, hipStream_t s, const float* pts, int n, const int32_t* sample_idx, int ns, double* out17);
 int bxk_refine(bx_ctx* c, hipStream_t s, const float* ss, const float* tt, const int32_t* M_dev, int max_M, float* T_io,
                int32_t* iters_out);
 

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void ball_rows_kernel(const int32_t* __restric
     const int ny = yhi - ylo + 1, nz = zhi - zlo + 1;
     const int R = ny * nz;
     int2 e = make_int2(0, 0);
-    if (R <= 63) {
+    if (R <= MAXROWS) {
         if (lane < R) {
             const int cz = zlo + lane / ny, cy = ylo + lane % ny;
             const int rowc = (cz * dy + cy) * dx;

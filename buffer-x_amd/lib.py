@@ -42,7 +42,8 @@ class BxResult(C.Structure):
 EXPORTS = ["bx_create", "bx_destroy", "bx_last_error", "bx_load_weights", "bx_workspace_bytes", "bx_register_pair",
            "bx_profile_enable", "bx_profile_read", "bx_debug_read",
            "bx_fps", "bx_radius", "bx_permute", "bx_ball_group", "bx_patch_features", "bx_desc_net", "bx_conv_layer",
-           "bx_mutual", "bx_pose_net", "bx_hypotheses", "bx_consensus", "bx_ransac", "bx_refine"]
+           "bx_mutual", "bx_pose_net", "bx_hypotheses", "bx_consensus", "bx_ransac", "bx_refine",
+           "bx_pre_reserve", "bx_pre_voxel_downsample", "bx_pre_pca"]
 
 
 def build(force=False):
@@ -243,6 +244,30 @@ class Context:
                                     C.c_int32(K), self._p(radius_dev), C.c_int32(P), self._p(idx), self._p(patches)),
              "bx_ball_group")
         return idx, patches
+
+    # ---------------------------------------------------------------- pre-processing
+    def pre_reserve(self, max_points):
+        _chk(self.lib.bx_pre_reserve(self.handle, C.c_int64(int(max_points))), "bx_pre_reserve")
+
+    def pre_voxel_downsample(self, pts, voxel_size):
+        """-> (out float32 [n,3] device tensor (first m rows valid), count device int32[2] = {m, status})"""
+        t = self.torch
+        pts = self._dev(pts, t.float32)
+        n = pts.shape[0]
+        out = self._empty((n, 3), t.float32)
+        cnt = self._empty((2,), t.int32)
+        _chk(self.lib.bx_pre_voxel_downsample(self.handle, self._stream(), self._p(pts), C.c_int32(n), C.c_double(float(voxel_size)),
+                                              self._p(out), self._p(cnt)), "bx_pre_voxel_downsample")
+        return out, cnt
+
+    def pre_pca(self, pts, sample_idx):
+        t = self.torch
+        pts = self._dev(pts, t.float32)
+        idx = self._dev(sample_idx, t.int32)
+        out = self._empty((17,), t.float64)
+        _chk(self.lib.bx_pre_pca(self.handle, self._stream(), self._p(pts), C.c_int32(pts.shape[0]), self._p(idx),
+                                 C.c_int32(idx.shape[0]), self._p(out)), "bx_pre_pca")
+        return out
 
     def patch_features(self, patches, radius_dev, aligned):
         t = self.torch

@@ -1,0 +1,55 @@
+"""Mirror of the reference's per-pair pre-processing on top of the HIP entry points bx_pre_* (SURVEY.md §8f rank 1):
+
+    sphericity_based_voxel_analysis(src_pts, tgt_pts)   <- utils/tools.py:152-198 (+ compute_pca_alignment :132-149)
+    voxel_down_sample(pts, voxel_size)                   <- o3d.geometry.PointCloud.voxel_down_sample as called at
+                                                            dataset/threedmatch.py:90-102, dataset/kitti.py, dataset/tiers.py
+
+Same names, argument meaning and return values as the reference functions (which take Open3D point clouds; here float32
+[n,3] arrays / device tensors).  The random 10 % subsample is drawn with the reference's own call, np.random.choice(num_points,
+size=int(num_points / 10), replace=False), in the same order (src, then tgt), so seeding NumPy reproduces it.  There is no CPU
+fallback: the PCA statistics, the z-range over the full cloud and the voxel grid run on the GPU."""
+import numpy as np
+
+from . import lib as _lib
+
+
+class Preprocessor:
+    def __init__(self, ctx, max_points):
+        self.ctx = ctx
+        ctx.pre_reserve(max_points)
+
+    def _pca(self, pts_dev, num_points):
+        idx = np.random.choice(num_points, size=int(num_points / 10), replace=False).astype(np.int32)
+        st = self.ctx.pre_pca(pts_dev, idx).cpu().numpy()
+        ev, comp, mean = st[0:3], st[3:12].reshape(3, 3), st[12:15]
+        l1, l2, l3 = sorted(ev, reverse=True)
+        sphericity = l3 / l1
+        z = comp[-1] / np.linalg.norm(comp[-1])
+        is_aligned = abs(float(np.dot(z, np.array([0, 0, 1])))) > 0.98
+        return sphericity, is_aligned, comp, float(st[16] - st[15])
+
+    def sphericity_based_voxel_analysis(self, src_pts, tgt_pts):
+        """-> (voxel_size, sphericity, is_aligned_to_global_z)   (utils/tools.py:152-198)"""
+        t = self.ctx.torch
+        src = self.ctx._dev(src_pts, t.float32)
+        tgt = self.ctx._dev(tgt_pts, t.float32)
+        s_src, a_src, c_src, zr_src = self._pca(src, src.shape[0])
+        s_tgt, a_tgt, c_tgt, zr_tgt = self._pca(tgt, tgt.shape[0])
+        if src.shape[0] > tgt.shape[0]:
+            sphericity, z_range = s_src, zr_src
+        else:
+            sphericity, z_range = s_tgt, zr_tgt
+        alpha = 1.0 if sphericity < 0.05 else 1.5
+        voxel_size = max(np.sqrt(z_range) / 100 * alpha, 0.001)
+        zs = c_src[-1] / np.linalg.norm(c_src[-1])
+        zt = c_tgt[-1] / np.linalg.norm(c_tgt[-1])
+        same_direction = float(np.dot(zs, zt)) > 0.96
+        return round(float(voxel_size), 4), float(sphericity), bool(a_src and a_tgt and same_direction)
+
+    def voxel_down_sample(self, pts, voxel_size):
+        """-> float32 device tensor [m,3] (order of first appearance; the loaders shuffle afterwards)"""
+        out, cnt = self.ctx.pre_voxel_downsample(pts, voxel_size)
+        m, status = (int(v) for v in cnt.cpu().numpy())
+        if status:
+            raise _lib.BxError("voxel size too small for the extent of the cloud (more than 2^21 voxels along an axis)")
+        return out[:m]

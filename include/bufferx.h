@@ -199,6 +199,25 @@ int bx_ransac(bx_ctx *ctx, void *stream, const float *ss, const float *tt, const
 int bx_refine(bx_ctx *ctx, void *stream, const float *ss, const float *tt, const int32_t *M_dev, int32_t max_M,
               float *T_io, int32_t *iters_out);
 
+/* ---- pre-processing in front of the hot path (optional: the hot path does not depend on it) ----------
+ * The reference prepares every pair on the host: utils/tools.py:152-198 sphericity_based_voxel_analysis (scikit-learn PCA of a
+ * 10 % subsample, z-range in the PCA frame -> voxel size) and open3d voxel_down_sample (dataset/threedmatch.py:90-102,
+ * dataset/kitti.py, dataset/tiers.py).  These entry points move both onto the GPU; buffer-x_amd/preprocess.py is the mirror of
+ * the two reference functions on top of them.
+ *
+ * bx_pre_reserve: workspace for clouds of up to max_points RAW points (<= 2^26; memory O(max_points) whatever the extent of the
+ * scene -- the voxels live in a hash table; allocates, not stream-ordered; call once).
+ * bx_pre_voxel_downsample: pts float32 [n][3] -> out float32 [<= n][3] voxel centroids (binary64 accumulation in input order like
+ * Open3D's AddPoint loop, emitted in order of first appearance); count_out device int32[2] = {number of voxels, status
+ * (1 = more than 2^21 voxels along an axis, i.e. the voxel size is too small for the extent: nothing written)}.
+ * bx_pre_pca: PCA (covariance + symmetric eigen-decomposition, sklearn sign convention) of pts[sample_idx[0..ns)] and the extent of
+ * ALL n points along the 3rd component.  out17 device double[17] = {explained_variance[3] descending, components[3][3] rows,
+ * mean[3], zmin, zmax}.                                                                                              */
+int bx_pre_reserve(bx_ctx *ctx, int64_t max_points);
+int bx_pre_voxel_downsample(bx_ctx *ctx, void *stream, const float *pts, int32_t n, double voxel_size, float *out,
+                            int32_t *count_out);
+int bx_pre_pca(bx_ctx *ctx, void *stream, const float *pts, int32_t n, const int32_t *sample_idx, int32_t ns, double *out17);
+
 #ifdef __cplusplus
 }
 #endif
