@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--inflight", type=int, default=3, help="pairs in flight per GPU (contexts / HIP streams)")
+    ap.add_argument("--lane", type=int, default=0, help="bx_lane mode ordering the pairs in flight: 0 none, 1 whole main phase, 2 conv stacks")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs per rank (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--num-fps", type=int, default=5000)
@@ -99,6 +100,9 @@ def main():
     C = max(1, args.inflight)
     ctxs = [lib.Context(cfg, max_points=60000, device=local, packed_weights=pw) for _ in range(C)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(C)]
+    lane = lib.Lane(args.lane) if args.lane and C > 1 else None
+    for cx in ctxs:
+        cx.attach_lane(lane)
     results = [ctxs[i].new_result() for i in range(C)]
 
     def run(n_steps, timed):

@@ -615,6 +615,52 @@ int bx_pre_pca(bx_ctx* c, void* stream, const float* pts, int32_t n, const int32
     return bxk_pre_pca(c, (hipStream_t)stream, pts, n, sample_idx, ns, out17);
 }
 
+// ------------------------------------------------------------------------------------------------ lane
+int bx_lane_create(int32_t mode, bx_lane** out)
+{
+    if (!out || mode < 1 || mode > 2) { bx_set_error("bx_lane_create: mode must be 1 or 2"); return BX_ERR_ARG; }
+    bx_lane* l = new bx_lane();
+    for (int i = 0; i < bx_lane::NEV; ++i) {
+        hipError_t e = hipEventCreateWithFlags(&l->ev[i], hipEventDisableTiming);
+        if (e != hipSuccess) { bx_set_error("bx_lane_create: hipEventCreate failed: %s", hipGetErrorString(e)); delete l; return BX_ERR_HIP; }
+    }
+    l->next = 0; l->last = -1; l->mode = mode;
+    *out = l;
+    return BX_OK;
+}
+
+int bx_lane_destroy(bx_lane* l)
+{
+    if (!l) return BX_OK;
+    for (int i = 0; i < bx_lane::NEV; ++i) (void)hipEventDestroy(l->ev[i]);
+    delete l;
+    return BX_OK;
+}
+
+int bx_attach_lane(bx_ctx* c, bx_lane* lane)
+{
+    if (!c) { bx_set_error("bx_attach_lane: null context"); return BX_ERR_ARG; }
+    c->lane = lane;
+    return BX_OK;
+}
+
+namespace {
+struct LaneScope {   // section of a pair that takes its turn on the lane
+    bx_lane* l; hipStream_t s;
+    LaneScope(bx_ctx* c, hipStream_t st, int mode) : l(c->lane && c->lane->mode == mode ? c->lane : nullptr), s(st)
+    {
+        if (l && l->last >= 0) (void)hipStreamWaitEvent(s, l->ev[l->last], 0);
+    }
+    ~LaneScope()
+    {
+        if (!l) return;
+        (void)hipEventRecord(l->ev[l->next], s);
+        l->last = l->next;
+        l->next = (l->next + 1) % bx_lane::NEV;
+    }
+};
+}  // namespace
+
 // ------------------------------------------------------------------------------------------------ whole pair
 int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, const float* tgt, int32_t n_tgt, int32_t aligned_z,
                      const int32_t* perm_src, const int32_t* perm_tgt, uint64_t seed, bx_result* result)
@@ -640,6 +686,7 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
     const int32_t* perms[2] = {perm_src, perm_tgt};
     { ProfScope ps(c, s, 0); if ((rc = bxk_fps(c, s, clouds, ns, 2, KM, c->fps_idx, c->kpts)) != BX_OK) return rc; }
 
+    LaneScope lane_main(c, s, 1);
     // (2) radius estimation histogram: the LARGER cloud and its keypoints (models/BUFFERX.py:654-665), once per pair
     const int big = n_src > n_tgt ? 0 : 1;
     const float* rpts = clouds[big];
@@ -662,10 +709,10 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
             c->ball_waves_hint = p.search_radius_thresholds[i] >= 1.5 ? 4 : 2;
             { ProfScope ps(c, s, 2); if ((rc = bxk_ball_group(c, s, c->pts_perm, ns[cl], c->kpts[cl], K, &st->des_r[i], P, c->ball_idx, c->patches)) != BX_OK) return rc; }
             { ProfScope ps(c, s, 3); if ((rc = bxk_patch_features(c, s, c->patches, K, P, &st->des_r[i], aligned_z, c->Rpatch[cl], c->feat)) != BX_OK) return rc; }
-            { ProfScope ps(c, s, 4); if ((rc = desc_stack(c, s, c->feat, K, c->desc_out[cl], c->equi[cl], nullptr)) != BX_OK) return rc; }
+            { LaneScope ls(c, s, 2); ProfScope ps(c, s, 4); if ((rc = desc_stack(c, s, c->feat, K, c->desc_out[cl], c->equi[cl], nullptr)) != BX_OK) return rc; }
         }
         { ProfScope ps(c, s, 6); if ((rc = bxk_mutual(c, s, c->desc_out[0], K, c->desc_out[1], K, c->s_mids, c->t_mids, &st->m_scale)) != BX_OK) return rc; }
-        { ProfScope ps(c, s, 7); if ((rc = pose_stack(c, s, c->equi[0], c->equi[1], c->s_mids, c->t_mids, &st->m_scale, K, c->ind, nullptr)) != BX_OK) return rc; }
+        { LaneScope ls(c, s, 2); ProfScope ps(c, s, 7); if ((rc = pose_stack(c, s, c->equi[0], c->equi[1], c->s_mids, c->t_mids, &st->m_scale, K, c->ind, nullptr)) != BX_OK) return rc; }
         if ((rc = bxk_hypotheses(s, c->ind, c->s_mids, c->t_mids, &st->m_scale, K, c->Rpatch[0], c->Rpatch[1], c->kpts[0], c->kpts[1],
                                  c->R_cat, c->t_cat, c->ss_cat, c->tt_cat, &st->M, c->skip)) != BX_OK) return rc;
         hipLaunchKernelGGL(accumulate_kernel, dim3(1), dim3(64), 0, s, st, i, c->skip);

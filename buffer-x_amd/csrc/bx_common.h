@@ -70,6 +70,17 @@ struct BallGrid {
 int bx_ball_div();
 void bx_prof_mark(bx_ctx* c, hipStream_t s, int tag, int begin);   // hipEvent bracket (bx_profile_*), no-op unless enabled
 
+// One lane per GPU: the convolution stacks of the pairs in flight on different contexts / streams run one after the other
+// (in submission order) instead of interleaving workgroup by workgroup, while everything latency-bound (FPS, RANSAC, the small
+// kernels) still overlaps with them.  Events are recorded round-robin from a ring; a wait captures the latest record.
+struct bx_lane {
+    static constexpr int NEV = 64;
+    hipEvent_t ev[NEV];
+    int next;      // ring position of the next record
+    int last;      // ring position of the latest record, -1: none yet
+    int mode;      // 1: whole main phase (everything after FPS), 2: conv stacks only
+};
+
 struct bx_ctx {
     int device;
     bx_params p;
@@ -129,6 +140,7 @@ struct bx_ctx {
     bx_result* result_dev;              // device staging of the result
     int32_t* err_flag;                  // device error flag
     const int32_t* skip;                // device flag: non-zero => pipeline kernels return immediately (early exit)
+    struct bx_lane* lane;               // optional: orders the MFMA-heavy sections of the pairs of several contexts (bx_attach_lane)
     void* pre;                          // bx_pre_ws* (k_pre.hip): workspace of the pre-processing entry points, reserved on demand
     int prof_on;
     void* prof;                         // std::vector<ProfEvt>* (bx_api.hip)

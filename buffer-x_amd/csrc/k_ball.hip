@@ -258,16 +258,20 @@ struct F3 { float x, y, z; };   // 4-byte aligned triple: stores compile to glob
 constexpr int QU = 8;            // candidate loads in flight per lane
 constexpr int MAXROWS = 63;      // (y,z) cell rows kept in the per-wave row table (one lane each)
 
-// Row tables of all keypoints, one wave per keypoint: lane k < R gets {first sorted-array slot, candidate count} of
-// the k-th (y,z) cell row around the keypoint; lane 63 carries R (or -1: degenerate geometry, the query kernel walks the
-// cells itself).  Doing this in its own launch takes one dependent memory round trip out of every query workgroup.
+// Row tables of all keypoints, one wave per keypoint.  The candidates of a keypoint are the points of the (y,z) cell rows around
+// it, every row trimmed to the chord of the ball; the non-empty rows are laid end to end into ONE flat candidate sequence.
+// Lane k < R gets {rs, pe} of the k-th non-empty row: pe = the row's end offset in the flat sequence, rs = its first slot in the
+// sorted array minus its flat start (flat position v of row k lives in sorted[rs + v]).  Lane 63 carries {R, T} (T = sequence
+// length) or {-1, 0}: degenerate geometry, the query kernel walks the cells itself.  Doing this in its own launch takes one
+// dependent memory round trip, a prefix scan and all empty rows out of every query workgroup.
 __global__ __launch_bounds__(256) void ball_rows_kernel(const int32_t* __restrict__ start, const BallGrid* __restrict__ g,
                                                         const float* __restrict__ kpts, int K, int2* __restrict__ rowtab,
-                                                        const int32_t* __restrict__ skip)
+                                                        int trim, const int32_t* __restrict__ skip)
 {
     if (skip && *skip) return;
-    const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ int2 comp[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wv;
     if (q >= K) return;
     const float qx = kpts[(size_t)q * 3], qy = kpts[(size_t)q * 3 + 1], qz = kpts[(size_t)q * 3 + 2];
     const float ox = g->ox, oy = g->oy, oz = g->oz, ih = g->inv_h, rp = g->rpad;
@@ -276,40 +280,76 @@ __global__ __launch_bounds__(256) void ball_rows_kernel(const int32_t* __restric
     const int ylo = cell_coord(qy - rp, oy, ih, dy), yhi = cell_coord(qy + rp, oy, ih, dy);
     const int zlo = cell_coord(qz - rp, oz, ih, dz), zhi = cell_coord(qz + rp, oz, ih, dz);
     const int ny = yhi - ylo + 1, nz = zhi - zlo + 1;
-    const int R = ny * nz;
-    int2 e = make_int2(0, 0);
-    if (R <= MAXROWS) {
-        if (lane < R) {
-            const int cz = zlo + lane / ny, cy = ylo + lane % ny;
-            const int rowc = (cz * dy + cy) * dx;
-            e.x = start[rowc + xlo];
-            e.y = start[rowc + xhi + 1] - e.x;
-        }
-        if (lane == 63) e = make_int2(R, 0);
-    } else if (lane == 63) {
-        e = make_int2(-1, 0);
+    const int R0 = ny * nz;
+    if (R0 > MAXROWS) {
+        rowtab[(size_t)q * 64 + lane] = make_int2(lane == 63 ? -1 : 0, lane == 63 ? 0 : 0x7fffffff);
+        return;
     }
-    rowtab[(size_t)q * 64 + lane] = e;
+    int st = 0, len = 0;
+    if (lane < R0) {
+        const int cz = zlo + lane / ny, cy = ylo + lane % ny;
+        const int rowc = (cz * dy + cy) * dx;
+        // chord trimming in cell units: every point of this row has u_y in [cy, cy+1], u_z in [cz, cz+1] (u = the value
+        // whose floor binned it), so a hit's |u_x - uq_x| is bounded by the chord of the (padded) ball at the row's
+        // smallest possible (y,z) distance.  DU covers the rounding of u (|u| <= 1024, two roundings) on both sides.
+        constexpr float DU = 1.0e-3f;
+        const float uqx = (qx - ox) * ih, uqy = (qy - oy) * ih, uqz = (qz - oz) * ih;
+        const float gy = fmaxf(fmaxf((float)cy - uqy, uqy - (float)(cy + 1)) - DU, 0.0f);
+        const float gz = fmaxf(fmaxf((float)cz - uqz, uqz - (float)(cz + 1)) - DU, 0.0f);
+        const float m = rp * ih + DU;
+        const float w2 = m * m - (gy * gy + gz * gz);
+        int xl = xlo, xh = xhi;
+        if (trim) {
+            if (w2 < 0.0f) { xl = 1; xh = 0; }
+            else {
+                const float w = sqrtf(w2) * 1.0001f + DU;
+                const float fl = fminf(fmaxf(floorf(uqx - w), 0.0f), (float)(dx - 1));
+                const float fh = fminf(fmaxf(floorf(uqx + w), 0.0f), (float)(dx - 1));
+                xl = max(xlo, (int)fl);
+                xh = min(xhi, (int)fh);
+            }
+        }
+        if (xl <= xh) {
+            st = start[rowc + xl];
+            len = start[rowc + xh + 1] - st;
+        }
+    }
+    // drop the empty rows (order kept), then the running end offsets
+    const unsigned long long live = __ballot(len > 0);
+    const int R = __popcll(live);
+    const int rank = __popcll(live & ((1ULL << lane) - 1ULL));
+    if (len > 0) comp[wv][rank] = make_int2(st, len);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
+    int2 e = lane < R ? comp[wv][lane] : make_int2(0, 0);
+    const int inc = bx_wave_incl_scan_dpp(e.y);
+    const int T = __builtin_amdgcn_readlane(inc, 63);
+    int2 o = make_int2(e.x - (inc - e.y), lane < R ? inc : 0x7fffffff);
+    if (lane == 63) o = make_int2(R, T);
+    rowtab[(size_t)q * 64 + lane] = o;
 }
 
 // QW waves per workgroup, ONE keypoint per workgroup (template parameter: 4 / 2 / 1 by the expected neighbourhood size)
 
-// Bit i of the hit bitmap: thread (i>>6) / CW owns CW = (1<<LOGC)/QW consecutive 64-bit words; its slot-th word sits at
-// bm64[slot*QT + thread] (conflict-free for the owners' ds_read_b64 sweep).
-template <int LOGC, int QW>
+// Bit i of the hit bitmap = bit (i & 31) of 32-bit word i >> 5 (plain layout: 2 VALU + ds_or per hit).
 __device__ __forceinline__ void set_hit(unsigned int* bm32, int i)
 {
-    constexpr int LQW = QW == 4 ? 2 : (QW == 2 ? 1 : 0);
-    constexpr int LCW = LOGC - LQW;               // log2(CW)
-    const int w = i >> 6;
-    const int a64 = ((w & ((1 << LCW) - 1)) << (6 + LQW)) + (w >> LCW);
-    atomicOr(&bm32[a64 * 2 + ((i >> 5) & 1)], 1u << (i & 31));
+    atomicOr(&bm32[i >> 5], 1u << (i & 31));
 }
 
-// One 4-wave workgroup per keypoint (one wave per keypoint left the kernel waiting for its slowest keypoints: the
-// candidate count varies 3x between keypoints; four waves per keypoint and 3-4 workgroup rounds even that out).
-// LOGC: log2 of the 64-bit bitmap words per 64 lanes (n <= 4096 << LOGC).  LDS: max(bitmap, index list) -- the list
-// overwrites the bitmap once every thread holds its words in registers.
+// QW-wave workgroup per keypoint (one wave per keypoint left the kernel waiting for its slowest keypoints: the candidate count
+// varies 3x between keypoints).  LOGC: log2 of the 64-bit bitmap words per 64 lanes (n <= 4096 << LOGC).
+// The kernel is VALU-issue bound (rocprofv3 SQ_INSTS_VALU: ~800 instructions per wave at 8 waves per SIMD), not memory bound:
+// the structure below is chosen for instruction count.
+//   1. candidates = the flat row sequence prepared by ball_rows_kernel, 64-candidate chunks dealt round-robin to the waves; the
+//      chunk -> row lookup is wave-uniform scalar code (readlane of the per-lane row table).
+//   2. hits set their bit in an LDS bitmap (bit = permuted point index): this restores the index order the reference's
+//      ball_query scans in, whatever order the grid delivered the candidates in.
+//   3. rank of a hit = set bits below it = prefix[word] + popcount(word & below): when all candidates of the keypoint were held in
+//      registers (one block of QU chunks per wave: the common case) every hit computes its own rank and drops its index into
+//      list[rank] -- no per-bit loops; otherwise the owners of the bitmap words expand their bits in order.
+//   4. output: gather + mask arithmetic from the ordered list, 768 contiguous bytes per wave store.
+// LDS: bitmap (n/8 B) | per-word prefix (n/16 B) | list (4 P B).
 template <int LOGC, int QW>
 __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __restrict__ sorted, const int32_t* __restrict__ start,
                                                         const BallGrid* __restrict__ g, const int2* __restrict__ rowtab,
@@ -321,54 +361,59 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
 {
     if (skip && *skip) return;
     constexpr int QT = 64 * QW;
+    constexpr int NW64 = 64 << LOGC;                    // 64-bit bitmap words
+    constexpr int CW = NW64 / QT;                       // consecutive bitmap words owned by a thread
+    static_assert(CW >= 2 && CW % 2 == 0, "a thread owns an even number of bitmap words");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int wtot[QW];
     long long t0 = 0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // SGPR: the chunk walk below is scalar code
     const int q = blockIdx.x;
     const bool tr = dbg != nullptr && (q % 79) == 0 && q / 79 < 60 && tid == 0;
     long long* td = dbg + (q / 79) * 8;
     if (tr) { t0 = __builtin_readcyclecounter(); td[0] = t0; }
 #define BX_TR(k) do { if (tr) td[k] = __builtin_readcyclecounter() - t0; } while (0)
-    constexpr int CW = (1 << LOGC) / QW;                // bitmap words per thread
     unsigned long long* bm64 = reinterpret_cast<unsigned long long*>(smem);
     unsigned int* bm32 = reinterpret_cast<unsigned int*>(smem);
-    int* list = reinterpret_cast<int*>(smem);           // [P], aliases the bitmap (see the hand-off below)
+    int* pre = reinterpret_cast<int*>(smem + (size_t)NW64 * 8);            // [NW64] set bits in front of every 64-bit word
+    int* list = reinterpret_cast<int*>(smem + (size_t)NW64 * 12);          // [P]
 
+    {
+        ulonglong2* z = reinterpret_cast<ulonglong2*>(bm64 + (size_t)tid * CW);
 #pragma unroll
-    for (int s = 0; s < CW; ++s) bm64[s * QT + tid] = 0ULL;
+        for (int s = 0; s < CW / 2; ++s) z[s] = make_ulonglong2(0ULL, 0ULL);
+    }
 
-    const int2 rt = rowtab[(size_t)q * 64 + lane];          // prepared by ball_rows_kernel
+    const int2 rt = rowtab[(size_t)q * 64 + lane];          // prepared by ball_rows_kernel: {rs, pe}; lane 63: {R, T}
     const float r = (float)(*radius);
     const float r2 = r * r;
     const float qx = kpts[(size_t)q * 3], qy = kpts[(size_t)q * 3 + 1], qz = kpts[(size_t)q * 3 + 2];
     const int R = __builtin_amdgcn_readlane(rt.x, 63);     // -1: degenerate geometry
+    const int T = __builtin_amdgcn_readlane(rt.y, 63);
+    const int rs = rt.x;
+    const int pe = lane == 63 ? 0x7fffffff : rt.y;
     BX_TR(1);
     __syncthreads();                                        // bitmap zeroed
+    if (tr) td[7] = T;
 
+    const bool one_block = R >= 0 && T <= QT * QU;          // uniform: every candidate is held in a register of some lane
+    int hidx[QU];                                           // one_block: index of the hit in slot u, -1 otherwise
     if (R >= 0) {
-        // ---- row table: every (y,z) row of cells is one contiguous range of the sorted array; the rows are laid end
-        //      to end into ONE flat candidate sequence.  Lane k of every wave keeps row k's flat end offset (pe) and
-        //      its sorted-array offset minus its flat start (rs); a 64-candidate chunk finds its rows with wave-uniform
-        //      readlanes (no LDS, no per-lane search).  The waves take the 64*QU-candidate blocks round-robin.
-        const int s_r = lane < R ? rt.x : 0, len = lane < R ? rt.y : 0;
-        const int inc = bx_wave_incl_scan_dpp(len);
-        const int T = __builtin_amdgcn_readlane(inc, 63);
-        const int rs = s_r - (inc - len);
-        const int pe = lane < R ? inc : 0x7fffffff;
-        BX_TR(2);
-        if (tr) td[7] = T;
-        int rb = 0;                                         // wave-uniform: first row whose end lies beyond the chunk start
-        for (int v0 = wave * 64 * QU; v0 < T; v0 += QW * 64 * QU) {
+        int rb = 0;                                         // wave-uniform (SGPR): first row whose end lies beyond the chunk start
+        for (int c0 = 0; c0 * 64 < T; c0 += QW * QU) {
+            // the loads of a block go out back to back and are waited for once (a load under a DIVERGENT branch is waited for
+            // right behind its issue: the merge with the not-taken value needs the data); chunks beyond T are skipped by
+            // scalar branches, lanes beyond T read slot 0 (a valid point) and are masked in the test
             float4 c[QU];
 #pragma unroll
             for (int u = 0; u < QU; ++u) {
-                const int vc = v0 + u * 64;                 // uniform chunk start
+                const int vc = (c0 + u * QW + wave) * 64;   // uniform chunk start
                 const int v = vc + lane;
-                c[u] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);   // never a hit (d2 = inf)
+                int addr = 0;
                 if (vc < T) {                               // uniform
                     while (__builtin_amdgcn_readlane(pe, rb) <= vc) ++rb;
-                    int addr = __builtin_amdgcn_readlane(rs, rb) + v;
+                    addr = __builtin_amdgcn_readlane(rs, rb) + v;
                     int k = rb;
                     int pek = __builtin_amdgcn_readlane(pe, k);
                     while (pek <= vc + 63) {                // uniform: a row boundary falls inside this chunk
@@ -377,14 +422,25 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
                         ++k;
                         pek = __builtin_amdgcn_readlane(pe, k);
                     }
-                    if (v < T) c[u] = sorted[addr];
+                    addr = v < T ? addr : 0;
                 }
+                // unconditional (a chunk beyond T re-reads slot 0): a load under a branch whose result merges with "not loaded"
+                // is waited for right behind its issue.  32-bit byte offset from the uniform base: ONE address VGPR (saddr form)
+                c[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sorted) + ((unsigned)addr << 4));
             }
 #pragma unroll
             for (int u = 0; u < QU; ++u) {
-                const float ax = qx - c[u].x, ay = qy - c[u].y, az = qz - c[u].z;
-                const float d2 = (ax * ax + ay * ay) + az * az;
-                if (d2 < r2) set_hit<LOGC, QW>(bm32, __float_as_int(c[u].w));
+                const int vc = (c0 + u * QW + wave) * 64;
+                hidx[u] = -1;
+                if (vc < T) {                               // uniform
+                    const float ax = qx - c[u].x, ay = qy - c[u].y, az = qz - c[u].z;
+                    const float d2 = (ax * ax + ay * ay) + az * az;
+                    if (d2 < r2 && vc + lane < T) {
+                        const int i = __float_as_int(c[u].w);
+                        set_hit(bm32, i);
+                        hidx[u] = i;
+                    }
+                }
             }
         }
     } else {
@@ -404,22 +460,22 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
                     const float4 a = sorted[k];
                     const float ax = qx - a.x, ay = qy - a.y, az = qz - a.z;
                     const float d2 = (ax * ax + ay * ay) + az * az;
-                    if (d2 < r2) set_hit<LOGC, QW>(bm32, __float_as_int(a.w));
+                    if (d2 < r2) set_hit(bm32, __float_as_int(a.w));
                 }
             }
     }
     __syncthreads();
     BX_TR(3);
 
-    // ---- ordered expansion of the first P set bits: thread t owns indices [t*64*CW, (t+1)*64*CW); its words move to
-    //      registers, then the index list is written over the bitmap
-    unsigned long long word[CW];
+    // ---- set bits in front of every thread's CW words (thread t owns indices [t*64*CW, (t+1)*64*CW)); the words are re-read
+    //      from LDS where they are needed again instead of being held in registers (64-VGPR budget: 8 waves per SIMD)
+    const ulonglong2* wsrc = reinterpret_cast<const ulonglong2*>(bm64 + (size_t)tid * CW);
     int tot = 0;
-#pragma unroll
-    for (int s = 0; s < CW; ++s) { word[s] = bm64[s * QT + tid]; tot += __popcll(word[s]); }
+#pragma unroll 4
+    for (int s = 0; s < CW / 2; ++s) { const ulonglong2 t2 = wsrc[s]; tot += __popcll(t2.x) + __popcll(t2.y); }
     const int inc = bx_wave_incl_scan_dpp(tot);
     if (lane == 63) wtot[wave] = inc;
-    __syncthreads();                                        // every thread has read its bitmap words; wave totals visible
+    __syncthreads();                                        // wave totals visible
     int pos = inc - tot, run = 0;
 #pragma unroll
     for (int w = 0; w < QW; ++w) {
@@ -427,10 +483,36 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
         if (w < wave) pos += wt;
         run += wt;
     }
-    if (tot > 0 && pos < P) {
+    const int nhit = run < P ? run : P;
+    if (one_block) {
+        // every hit ranks itself: set bits in front of its word + set bits below it inside the word
+        {
+            int2* pd = reinterpret_cast<int2*>(pre + (size_t)tid * CW);
+            int pp = pos;
+#pragma unroll 4
+            for (int s = 0; s < CW / 2; ++s) {
+                const ulonglong2 t2 = wsrc[s];
+                const int p1 = pp + __popcll(t2.x);
+                pd[s] = make_int2(pp, p1);
+                pp = p1 + __popcll(t2.y);
+            }
+        }
+        __syncthreads();
 #pragma unroll
+        for (int u = 0; u < QU; ++u) {
+            const int i = hidx[u];
+            if (i >= 0) {
+                const int w = i >> 6;
+                const unsigned long long below = bm64[w] & ((1ULL << (i & 63)) - 1ULL);
+                const int rank = pre[w] + __popcll(below);
+                if (rank < P) list[rank] = i;
+            }
+        }
+    } else if (tot > 0 && pos < P) {
+        // owners expand their bits in order
+#pragma unroll 2
         for (int s = 0; s < CW; ++s) {
-            unsigned long long w = word[s];
+            unsigned long long w = bm64[(size_t)tid * CW + s];
             const int base = (tid * CW + s) << 6;
             while (w != 0ULL && pos < P) {
                 const int b = __ffsll((long long)w) - 1;
@@ -439,7 +521,6 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
             }
         }
     }
-    const int nhit = run < P ? run : P;
     __syncthreads();
     BX_TR(4);
 
@@ -447,7 +528,7 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
     const int first = nhit > 0 ? list[0] : 0;
     F3* out3 = reinterpret_cast<F3*>(patches) + (size_t)q * P;
     int32_t* outi = idx_out ? idx_out + (size_t)q * P : nullptr;
-    constexpr int OU = 4;
+    constexpr int OU = QW >= 4 ? 4 : 8;     // P = 1024: one pass, every gather of the keypoint in flight at once
     for (int j0 = 0; j0 < P; j0 += QT * OU) {
         int idx[OU];
         float4 p[OU];
@@ -457,7 +538,7 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
             idx[u] = j < nhit ? list[j] : first;
         }
 #pragma unroll
-        for (int u = 0; u < OU; ++u) p[u] = pts4[idx[u]];
+        for (int u = 0; u < OU; ++u) p[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(pts4) + ((unsigned)idx[u] << 4));
 #pragma unroll
         for (int u = 0; u < OU; ++u) {
             const int j = j0 + u * QT + tid;
@@ -482,8 +563,7 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
 template <int LOGC, int QW>
 int launch_query_w(bx_ctx* c, hipStream_t s, int K, const float* kpts, const double* radius, int P, int32_t* idx_out, float* patches_out)
 {
-    const size_t bm = ((size_t)64 << LOGC) * 8, li = (size_t)P * 4;
-    const size_t lds = bm > li ? bm : li;
+    const size_t lds = ((size_t)64 << LOGC) * 12 + (size_t)P * 4;   // bitmap | per-word prefix | ordered index list
     if (lds > 160 * 1024) { bx_set_error("bxk_ball_group: P=%d needs %zu B of LDS per keypoint (> 160 KiB)", P, lds); return BX_ERR_ARG; }
     if (lds > 64 * 1024 && !(c->ball_attr_set & (1LL << (LOGC * 3 + QW / 2)))) {
         BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_kernel<LOGC, QW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -502,12 +582,21 @@ int launch_query(bx_ctx* c, hipStream_t s, int K, const float* kpts, const doubl
     // per-keypoint chain of dependent memory round trips dominates and more independent workgroups hide it better)
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("BX_BALL_WAVES"); forced = e ? atoi(e) : 0; }
-    const int w = forced ? forced : c->ball_waves_hint;
+    // measured (K = 5000, P = 1024): 4 waves win whenever the bitmap sweep is long (n > 32768: LOGC >= 4) or the neighbourhood is
+    // large (hint from the radius threshold); 2 waves only for small neighbourhoods in small clouds
+    const int w = forced ? forced : (LOGC >= 4 ? 4 : c->ball_waves_hint);
     if (w >= 4) return launch_query_w<LOGC, 4>(c, s, K, kpts, radius, P, idx_out, patches_out);
     if (w == 1) return launch_query_w<LOGC, 1>(c, s, K, kpts, radius, P, idx_out, patches_out);
     return launch_query_w<LOGC, 2>(c, s, K, kpts, radius, P, idx_out, patches_out);
 }
 }  // namespace
+
+static int bx_ball_trim()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("BX_BALL_TRIM"); v = e ? atoi(e) : 1; }
+    return v;
+}
 
 int bx_ball_div()
 {
@@ -549,7 +638,7 @@ int bxk_ball_group(bx_ctx* c, hipStream_t s, const float* pts_perm, int n, const
     hipLaunchKernelGGL(scan_sums_kernel, dim3(ntile), dim3(256), 0, s, c->ball_cnt, c->ball_grid, c->ball_bsum, skip);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(ntile), dim3(256), 0, s, c->ball_cnt, c->ball_grid, c->ball_bsum, c->ball_start, skip);
     hipLaunchKernelGGL(cell_scatter_kernel, dim3(nb), dim3(256), 0, s, c->ball_pts4, n, c->ball_cellrank, c->ball_start, c->ball_sorted, skip);
-    hipLaunchKernelGGL(ball_rows_kernel, dim3((K + 3) / 4), dim3(256), 0, s, c->ball_start, c->ball_grid, kpts, K, c->ball_rowtab, skip);
+    hipLaunchKernelGGL(ball_rows_kernel, dim3((K + 3) / 4), dim3(256), 0, s, c->ball_start, c->ball_grid, kpts, K, c->ball_rowtab, bx_ball_trim(), skip);
     bx_prof_mark(c, s, 12, 1);
     int rc = BX_OK;
     switch (logc) {

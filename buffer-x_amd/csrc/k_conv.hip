@@ -61,6 +61,12 @@ struct ConvCfg {
     // cylindrical 3x3 layers: tap offsets are compile-time constants -> the tap loop is unrolled and the offset rides in the
     // ds_read's immediate field (no address add per tile)
     static constexpr bool CYLG = NTAPS == 9 && P_IN == BX_EA && P_LDS == (BX_ELE + 2) * (BX_AZI + 2);
+    // un-padded 3x3 layers on a square VW x VW map (CostNet's k(3,1,3) layers): same treatment, row stride VW
+    static constexpr int isq(int v) { int r = 0; while ((r + 1) * (r + 1) <= v) ++r; return r; }
+    static constexpr int VW = isq(P_IN);
+    static constexpr bool VALG = NTAPS == 9 && P_LDS == P_IN && VW * VW == P_IN && (VW - 2) * (VW - 2) == P_OUT;
+    static constexpr bool ST9 = CYLG || VALG;                  // static 9-tap schedule
+    static constexpr int TAPW = CYLG ? BX_AZI + 2 : VW;        // LDS rows between two tap rows
     static_assert(NT % NPW == 0 && WN <= NW && NW % WN == 0, "waves must tile the output channels");
     static_assert(LDS_BYTES <= 160 * 1024, "slab double buffer exceeds the LDS");
     static_assert(NTAPS <= 64, "tap offsets live in one lane each");
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
     };
     float bc[NPW][4], bn[NPW][4];
     loadB(0, bc);
-    if constexpr (C::CYLG) loadB(1, bn);
+    if constexpr (C::ST9) loadB(1, bn);
     else {
 #pragma unroll
         for (int j = 0; j < NPW; ++j)
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
 #pragma unroll
         for (int t = 0; t < C::TPW; ++t) ab[t] = lb + abase[t];
         auto do_tap = [&](int tp, const float (&b_)[NPW][4]) {
-            const int tb = C::CYLG ? ((tp / 3) * (BX_AZI + 2) + tp % 3) * (ROWF * 4) : __builtin_amdgcn_readlane(toffv, tp);
+            const int tb = C::ST9 ? ((tp / 3) * C::TAPW + tp % 3) * (ROWF * 4) : __builtin_amdgcn_readlane(toffv, tp);
             f32x4 a[C::TPW];
             a[0] = *reinterpret_cast<const f32x4*>(ab[0] + tb);
             if (C::TPW > 1) a[C::TPW > 1 ? 1 : 0] = *reinterpret_cast<const f32x4*>(ab[C::TPW > 1 ? 1 : 0] + tb);
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        if constexpr (C::CYLG) {
+        if constexpr (C::ST9) {
             // Unrolled 9-tap schedule, B fragments requested TWO taps ahead (one tap of MFMAs is not always longer than an
             // L2 round trip under load); the fragments of the next chunk's taps 0 and 1 and then the next slab go out at
             // tap 6, so nothing issued after the slab load is waited for before the LDS hand-off (vmcnt retires in order).

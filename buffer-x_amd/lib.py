@@ -43,7 +43,8 @@ EXPORTS = ["bx_create", "bx_destroy", "bx_last_error", "bx_load_weights", "bx_wo
            "bx_profile_enable", "bx_profile_read", "bx_debug_read",
            "bx_fps", "bx_radius", "bx_permute", "bx_ball_group", "bx_patch_features", "bx_desc_net", "bx_conv_layer",
            "bx_mutual", "bx_pose_net", "bx_hypotheses", "bx_consensus", "bx_ransac", "bx_refine",
-           "bx_pre_reserve", "bx_pre_voxel_downsample", "bx_pre_pca"]
+           "bx_pre_reserve", "bx_pre_voxel_downsample", "bx_pre_pca",
+           "bx_lane_create", "bx_lane_destroy", "bx_attach_lane"]
 
 
 def build(force=False):
@@ -126,6 +127,21 @@ def logical_to_chunked(x):
     return np.ascontiguousarray(x[..., inv])
 
 
+class Lane:
+    """bx_lane: the contexts attached to one Lane run their MFMA-bound sections one after the other (mode 1: everything after
+    the FPS; mode 2: the convolution stacks)."""
+
+    def __init__(self, mode=2):
+        self.lib = load()
+        self.handle = C.c_void_p()
+        _chk(self.lib.bx_lane_create(C.c_int32(int(mode)), C.byref(self.handle)), "bx_lane_create")
+
+    def close(self):
+        if self.handle:
+            self.lib.bx_lane_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
 class Context:
     """One per in-flight pair: owns the device workspace arena (include/bufferx.h bx_ctx)."""
 
@@ -141,6 +157,11 @@ class Context:
         self._keep = []
         if packed_weights is not None:
             self.load_weights(packed_weights)
+
+    def attach_lane(self, lane):
+        """lane: Lane or None (see include/bufferx.h: ordering of the pairs in flight on one GPU)"""
+        _chk(self.lib.bx_attach_lane(self.handle, lane.handle if lane is not None else C.c_void_p()), "bx_attach_lane")
+        self._lane = lane
 
     def close(self):
         if self.handle:

@@ -43,6 +43,7 @@ extern "C" {
 #define BX_MAX_SCALES 8
 
 typedef struct bx_ctx bx_ctx;
+typedef struct bx_lane bx_lane;
 
 /* Hot-path knobs == reference cfg.patch / cfg.match / cfg.test fields (config/indoor_config.py:49-80,
  * config/outdoor_config.py:49-82; CLI overrides utils/test_args.py:46-63). */
@@ -198,6 +199,16 @@ int bx_ransac(bx_ctx *ctx, void *stream, const float *ss, const float *tt, const
  * iters_out device int32 [1] (nullable).                                                        */
 int bx_refine(bx_ctx *ctx, void *stream, const float *ss, const float *tt, const int32_t *M_dev, int32_t max_M,
               float *T_io, int32_t *iters_out);
+
+/* ---- lane: ordering of the pairs in flight on ONE GPU (optional) -----------------------------------------------------------
+ * The reference runs one pair at a time (test.py:132-146).  Here several contexts / streams keep pairs in flight so that the
+ * latency-bound furthest-point sampling of one pair overlaps the convolutions of another.  Contexts attached to the same lane
+ * additionally run their MFMA-bound sections one after the other, in submission order, instead of interleaving them workgroup by
+ * workgroup: mode 1 = everything after the FPS, mode 2 = the two convolution stacks only.  Results do not depend on it.
+ * Calls that use a lane must come from one host thread (or be serialised by the caller).                                     */
+int bx_lane_create(int32_t mode, bx_lane **out);
+int bx_lane_destroy(bx_lane *lane);
+int bx_attach_lane(bx_ctx *ctx, bx_lane *lane);          /* lane == NULL detaches */
 
 /* ---- pre-processing in front of the hot path (optional: the hot path does not depend on it) ----------
  * The reference prepares every pair on the host: utils/tools.py:152-198 sphericity_based_voxel_analysis (scikit-learn PCA of a
