@@ -119,6 +119,7 @@ void carve(bx_ctx* c, char* base, size_t* total)
     c->ball_bsum = cv.take<int32_t>(BX_BALL_NCELL / 2048 + 2);
     c->ball_cellrank = cv.take<int2>(NMAX);
     c->ball_rowtab = cv.take<int2>(KM * 64);
+    c->ball_chunktab = cv.take<int4>(KM * 64);
     c->ball_pts4 = cv.take<float4>(NMAX);
     c->ball_sorted = cv.take<float4>(NMAX);
     c->ball_dbg = cv.take<long long>(64 * 8);

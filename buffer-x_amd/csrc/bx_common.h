@@ -132,6 +132,7 @@ struct bx_ctx {
     int32_t* ball_bsum;                 // per scan tile
     int2* ball_cellrank;                // [max_points]
     int2* ball_rowtab;                  // [num_fps][64] per-keypoint candidate row table (ball_rows_kernel)
+    int4* ball_chunktab;                // [num_fps][64] per-keypoint chunk table {row-boundary mask lo, hi, rows in front, 0}
     float4 *ball_pts4, *ball_sorted;    // [max_points] {x,y,z,0} in permuted order / {x,y,z,bits(i)} sorted by cell
     long long ball_attr_set;
     int ball_waves_hint;                // waves per keypoint of the next neighbour-gather launch (0 = default 2)

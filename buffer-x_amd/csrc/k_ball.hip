@@ -266,10 +266,11 @@ constexpr int MAXROWS = 63;      // (y,z) cell rows kept in the per-wave row tab
 // dependent memory round trip, a prefix scan and all empty rows out of every query workgroup.
 __global__ __launch_bounds__(256) void ball_rows_kernel(const int32_t* __restrict__ start, const BallGrid* __restrict__ g,
                                                         const float* __restrict__ kpts, int K, int2* __restrict__ rowtab,
-                                                        int trim, const int32_t* __restrict__ skip)
+                                                        int4* __restrict__ chunktab, int trim, const int32_t* __restrict__ skip)
 {
     if (skip && *skip) return;
     __shared__ int2 comp[4][64];
+    __shared__ unsigned int cm[4][128];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wv;
     if (q >= K) return;
@@ -327,6 +328,20 @@ __global__ __launch_bounds__(256) void ball_rows_kernel(const int32_t* __restric
     int2 o = make_int2(e.x - (inc - e.y), lane < R ? inc : 0x7fffffff);
     if (lane == 63) o = make_int2(R, T);
     rowtab[(size_t)q * 64 + lane] = o;
+    // chunk table (T <= 4096: 64 chunks of 64 candidates): bit b of chunk j's mask = "a row ends at flat position 64 j + b"
+    // (position pe - 1), z = rows that ended in front of the chunk.  The row of flat position v = 64 j + l is then
+    // z_j + popcount(mask_j & lanes below l): two mbcnt instructions per chunk in the query kernel instead of a row walk.
+    if (T <= 4096) {
+        cm[wv][lane] = 0u; cm[wv][64 + lane] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < R) { const int pos = inc - 1; atomicOr(&cm[wv][pos >> 5], 1u << (pos & 31)); }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        const unsigned mlo = cm[wv][2 * lane], mhi = cm[wv][2 * lane + 1];
+        const int cnt = __popc(mlo) + __popc(mhi);
+        const int cinc = bx_wave_incl_scan_dpp(cnt);
+        chunktab[(size_t)q * 64 + lane] = make_int4((int)mlo, (int)mhi, cinc - cnt, 0);
+    }
 }
 
 // QW waves per workgroup, ONE keypoint per workgroup (template parameter: 4 / 2 / 1 by the expected neighbourhood size)
@@ -353,7 +368,7 @@ __device__ __forceinline__ void set_hit(unsigned int* bm32, int i)
 template <int LOGC, int QW>
 __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __restrict__ sorted, const int32_t* __restrict__ start,
                                                         const BallGrid* __restrict__ g, const int2* __restrict__ rowtab,
-                                                        const float4* __restrict__ pts4,
+                                                        const int4* __restrict__ chunktab, const float4* __restrict__ pts4,
                                                         const float* __restrict__ kpts, int K,
                                                         const double* __restrict__ radius, int P, int32_t* __restrict__ idx_out,
                                                         float* __restrict__ patches, const int32_t* __restrict__ skip,
@@ -386,6 +401,7 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
     }
 
     const int2 rt = rowtab[(size_t)q * 64 + lane];          // prepared by ball_rows_kernel: {rs, pe}; lane 63: {R, T}
+    const int4 ct = chunktab[(size_t)q * 64 + lane];        // chunk j: {boundary mask lo, hi, rows in front} (valid when T <= 4096)
     const float r = (float)(*radius);
     const float r2 = r * r;
     const float qx = kpts[(size_t)q * 3], qy = kpts[(size_t)q * 3 + 1], qz = kpts[(size_t)q * 3 + 2];
@@ -411,7 +427,13 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
                 const int vc = (c0 + u * QW + wave) * 64;   // uniform chunk start
                 const int v = vc + lane;
                 int addr = 0;
-                if (vc < T) {                               // uniform
+                if (vc < T && T <= 4096) {                  // uniform: chunk table -> row of every lane without a walk
+                    const int cj = vc >> 6;
+                    const unsigned mlo = (unsigned)__builtin_amdgcn_readlane(ct.x, cj), mhi = (unsigned)__builtin_amdgcn_readlane(ct.y, cj);
+                    const int row = __builtin_amdgcn_readlane(ct.z, cj) + (int)__builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+                    addr = __builtin_amdgcn_ds_bpermute(row << 2, rs) + v;
+                    addr = v < T ? addr : 0;
+                } else if (vc < T) {                        // uniform: long sequences walk the row table
                     while (__builtin_amdgcn_readlane(pe, rb) <= vc) ++rb;
                     addr = __builtin_amdgcn_readlane(rs, rb) + v;
                     int k = rb;
@@ -569,7 +591,7 @@ int launch_query_w(bx_ctx* c, hipStream_t s, int K, const float* kpts, const dou
         BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_kernel<LOGC, QW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         c->ball_attr_set |= 1 << (LOGC * 3 + QW / 2);
     }
-    hipLaunchKernelGGL((ball_query_kernel<LOGC, QW>), dim3(K), dim3(64 * QW), lds, s, c->ball_sorted, c->ball_start, c->ball_grid, c->ball_rowtab, c->ball_pts4, kpts, K,
+    hipLaunchKernelGGL((ball_query_kernel<LOGC, QW>), dim3(K), dim3(64 * QW), lds, s, c->ball_sorted, c->ball_start, c->ball_grid, c->ball_rowtab, c->ball_chunktab, c->ball_pts4, kpts, K,
                        radius, P, idx_out, patches_out, c->skip, getenv("BX_BALL_DEBUG") ? c->ball_dbg : nullptr);
     BX_LAUNCH_CHECK();
     return BX_OK;
@@ -638,7 +660,7 @@ int bxk_ball_group(bx_ctx* c, hipStream_t s, const float* pts_perm, int n, const
     hipLaunchKernelGGL(scan_sums_kernel, dim3(ntile), dim3(256), 0, s, c->ball_cnt, c->ball_grid, c->ball_bsum, skip);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(ntile), dim3(256), 0, s, c->ball_cnt, c->ball_grid, c->ball_bsum, c->ball_start, skip);
     hipLaunchKernelGGL(cell_scatter_kernel, dim3(nb), dim3(256), 0, s, c->ball_pts4, n, c->ball_cellrank, c->ball_start, c->ball_sorted, skip);
-    hipLaunchKernelGGL(ball_rows_kernel, dim3((K + 3) / 4), dim3(256), 0, s, c->ball_start, c->ball_grid, kpts, K, c->ball_rowtab, bx_ball_trim(), skip);
+    hipLaunchKernelGGL(ball_rows_kernel, dim3((K + 3) / 4), dim3(256), 0, s, c->ball_start, c->ball_grid, kpts, K, c->ball_rowtab, c->ball_chunktab, bx_ball_trim(), skip);
     bx_prof_mark(c, s, 12, 1);
     int rc = BX_OK;
     switch (logc) {
