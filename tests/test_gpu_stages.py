@@ -372,3 +372,22 @@ def test_ball_group_patch_larger_than_cloud(ctx, oracle):
     idx, patches = ctx.ball_group(pts, kp, torch.tensor([0.6], dtype=torch.float64), 128)
     ridx, rp = oracle.ball_group(pts, kp, np.float32(0.6), 128)
     assert np.array_equal(_np(idx), ridx) and np.array_equal(_np(patches), rp)
+
+
+@pytest.mark.parametrize("n,r,nkp", [(60000, 0.45, 64), (130000, 0.5, 40)])
+def test_ball_group_long_candidate_sequences(bx, oracle, packed, n, r, nkp):
+    """Dense cloud + large radius: candidate sequences longer than one register block (n = 60k: ~3600 candidates per keypoint,
+    chunk table + bit peeling) and longer than the 64-chunk table (n = 130k: ~10k candidates, row walk); 128k+ points also
+    exercise the 5-level bitmap."""
+    import torch
+    from bufferx_amd import lib
+    rng = np.random.default_rng(n)
+    pts = (rng.random((n, 3), np.float32) * 2).astype(np.float32)
+    kp = np.concatenate([pts[rng.choice(n, nkp - 8, replace=False)], (rng.random((8, 3), np.float32) * 2).astype(np.float32)])
+    c = lib.Context(_cfg(bx, K=256, P=128, S=2, nk=256), max_points=n, device=0, packed_weights=packed)
+    try:
+        idx, patches = c.ball_group(pts, kp, torch.tensor([r], dtype=torch.float64), 128)
+        ridx, rp = oracle.ball_group(pts, kp, np.float32(r), 128)
+        assert np.array_equal(_np(idx), ridx) and np.array_equal(_np(patches), rp)
+    finally:
+        c.close()
