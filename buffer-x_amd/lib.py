@@ -44,7 +44,9 @@ EXPORTS = ["bx_create", "bx_destroy", "bx_last_error", "bx_load_weights", "bx_wo
            "bx_fps", "bx_radius", "bx_permute", "bx_ball_group", "bx_patch_features", "bx_desc_net", "bx_conv_layer",
            "bx_mutual", "bx_pose_net", "bx_hypotheses", "bx_consensus", "bx_ransac", "bx_refine",
            "bx_pre_reserve", "bx_pre_voxel_downsample", "bx_pre_pca",
-           "bx_lane_create", "bx_lane_destroy", "bx_attach_lane"]
+           "bx_lane_create", "bx_lane_destroy", "bx_attach_lane",
+           "bx_io_probe", "bx_io_read_xyz", "bx_prefetch_create", "bx_prefetch_submit", "bx_prefetch_wait", "bx_prefetch_release",
+           "bx_prefetch_destroy"]
 
 
 def build(force=False):

@@ -44,6 +44,7 @@ extern "C" {
 
 typedef struct bx_ctx bx_ctx;
 typedef struct bx_lane bx_lane;
+typedef struct bx_prefetch bx_prefetch;
 
 /* Hot-path knobs == reference cfg.patch / cfg.match / cfg.test fields (config/indoor_config.py:49-80,
  * config/outdoor_config.py:49-82; CLI overrides utils/test_args.py:46-63). */
@@ -228,6 +229,31 @@ int bx_pre_reserve(bx_ctx *ctx, int64_t max_points);
 int bx_pre_voxel_downsample(bx_ctx *ctx, void *stream, const float *pts, int32_t n, double voxel_size, float *out,
                             int32_t *count_out);
 int bx_pre_pca(bx_ctx *ctx, void *stream, const float *pts, int32_t n, const int32_t *sample_idx, int32_t ns, double *out17);
+
+/* ---- data ingest in front of the hot path (optional) ----------------------------------------------
+ * The reference opens every pair synchronously on the main thread: open3d.io.read_point_cloud for .ply
+ * (dataset/threedmatch.py:75-79) and .pcd (dataset/tiers.py:72-73), np.fromfile(float32).reshape(-1, 4)[:, :3] for KITTI .bin
+ * (dataset/kitti.py:76-80), then a blocking .cuda().
+ *
+ * bx_io_probe: number of points of a .ply / .pcd / .bin file (header only for ply / pcd).
+ * bx_io_read_xyz: xyz of every point as float32 [n][3] into a HOST buffer of `capacity` points (PLY ascii / binary little / big
+ * endian with any scalar or list properties; PCD ascii / binary / binary_compressed; float64 coordinates are rounded to
+ * float32, which is what the loaders hand to the model).
+ * bx_prefetch_*: `slots` pairs of pinned host + device buffers of max_points points each and one worker thread.
+ *   submit  queues the two files of a pair; the worker parses them into pinned memory and uploads them with hipMemcpyAsync on
+ *           its own stream (returns BX_ERR_STATE when every slot is in use).
+ *   wait    blocks the HOST until the upload has been issued, makes `stream` wait for the DMA (hipStreamWaitEvent) and returns
+ *           the device pointers (owned by the prefetcher, valid until release).
+ *   release the slot may be refilled once everything queued on `stream` so far has run.
+ * One submitting / waiting host thread per prefetcher.                                                                       */
+int bx_io_probe(const char *path, int64_t *n_points);
+int bx_io_read_xyz(const char *path, float *xyz_out, int64_t capacity, int64_t *n_points);
+int bx_prefetch_create(int32_t device, int32_t slots, int64_t max_points, bx_prefetch **out);
+int bx_prefetch_submit(bx_prefetch *p, const char *src_path, const char *tgt_path, int64_t *ticket);
+int bx_prefetch_wait(bx_prefetch *p, int64_t ticket, void *stream, const float **src_dev, int64_t *n_src, const float **tgt_dev,
+                     int64_t *n_tgt);
+int bx_prefetch_release(bx_prefetch *p, int64_t ticket, void *stream);
+int bx_prefetch_destroy(bx_prefetch *p);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,105 @@
+"""Data ingest: the native readers (bx_io_*) against the format restatement in oracle/io_oracle.py and,
+for KITTI .bin, against the reference's own expression np.fromfile(...).reshape(-1, 4)[:, :3] (dataset/kitti.py:76-80).
+CPU only: no kernel is launched (the prefetcher has its own GPU test)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import io_oracle as IO
+
+
+@pytest.fixture(scope="module")
+def ing():
+    from bufferx_amd import ingest
+    return ingest
+
+
+def _cloud(n, seed=0, dtype=np.float32):
+    rng = np.random.default_rng(seed)
+    return (rng.normal(size=(n, 3)) * [3.0, 2.0, 0.5] + [1.0, -2.0, 0.25]).astype(dtype)
+
+
+@pytest.mark.parametrize("fmt", ["ascii", "binary_little_endian", "binary_big_endian"])
+@pytest.mark.parametrize("coord", ["float", "double"])
+def test_ply_plain(tmp_path, ing, fmt, coord):
+    pts = _cloud(2500, 1, np.float64 if coord == "double" else np.float32)
+    f = str(tmp_path / "c.ply")
+    IO.write_ply(f, pts, fmt, coord)
+    got = ing.read_point_cloud(f)
+    assert ing.probe(f) == 2500
+    assert got.dtype == np.float32 and np.array_equal(got, IO.read_ply(f)) and np.array_equal(got, pts.astype(np.float32))
+
+
+@pytest.mark.parametrize("fmt", ["ascii", "binary_little_endian", "binary_big_endian"])
+def test_ply_extra_properties_and_faces(tmp_path, ing, fmt):
+    """3DMatch fragments carry normals / colours; meshes carry a face element with a list property (before or after the vertices)."""
+    pts = _cloud(700, 2)
+    rng = np.random.default_rng(3)
+    extra = [("nx", "float", rng.normal(size=700).astype(np.float32)), ("red", "uchar", rng.integers(0, 255, 700)),
+             ("label", "short", rng.integers(-5, 5, 700))]
+    faces = rng.integers(0, 700, (40, 3))
+    for face_first in (False, True):
+        f = str(tmp_path / f"m{int(face_first)}.ply")
+        IO.write_ply(f, pts, fmt, "float", extra, faces, face_first, crlf=(fmt == "ascii"))
+        got = ing.read_point_cloud(f)
+        assert np.array_equal(got, pts) and np.array_equal(got, IO.read_ply(f))
+
+
+@pytest.mark.parametrize("mode", ["ascii", "binary", "binary_compressed"])
+@pytest.mark.parametrize("coord", ["F4", "F8"])
+def test_pcd(tmp_path, ing, mode, coord):
+    """TIERS .pcd: x y z intensity (+ ring); binary_compressed is LZF over a field-major layout."""
+    pts = _cloud(3100, 4, np.float64 if coord == "F8" else np.float32)
+    pts[100:400] = pts[100]            # constant stretches: back references in the LZF stream
+    f = str(tmp_path / "c.pcd")
+    IO.write_pcd(f, pts, mode, coord, extra=[("intensity", "F4", np.zeros(3100)), ("ring", "U2", np.arange(3100) % 64)])
+    got = ing.read_point_cloud(f)
+    assert ing.probe(f) == 3100
+    assert np.array_equal(got, IO.read_pcd(f)) and np.array_equal(got, pts.astype(np.float32))
+
+
+def test_kitti_bin_is_the_reference_expression(tmp_path, ing):
+    rng = np.random.default_rng(5)
+    xyzr = rng.normal(size=(12345, 4)).astype(np.float32)
+    f = str(tmp_path / "000000.bin")
+    xyzr.tofile(f)
+    ref = np.fromfile(f, dtype=np.float32).reshape(-1, 4)[:, :3]          # dataset/kitti.py:76-80
+    got = ing.read_point_cloud(f)
+    assert np.array_equal(got, ref) and np.array_equal(got, IO.read_kitti_bin(f))
+
+
+def test_empty_and_errors(tmp_path, ing):
+    from bufferx_amd import lib
+    f = str(tmp_path / "e.ply")
+    IO.write_ply(f, np.zeros((0, 3), np.float32))
+    assert ing.read_point_cloud(f).shape == (0, 3)
+    with pytest.raises(lib.BxError):
+        ing.read_point_cloud(str(tmp_path / "missing.ply"))
+    bad = str(tmp_path / "bad.bin")
+    open(bad, "wb").write(b"\0" * 20)                                     # not a multiple of 16 bytes
+    with pytest.raises(lib.BxError):
+        ing.read_point_cloud(bad)
+    trunc = str(tmp_path / "t.ply")
+    IO.write_ply(trunc, _cloud(100), "binary_little_endian")
+    raw = open(trunc, "rb").read()
+    open(trunc, "wb").write(raw[:-50])
+    with pytest.raises(lib.BxError):
+        ing.read_point_cloud(trunc)
+    with pytest.raises(lib.BxError):
+        ing.read_point_cloud(str(tmp_path / "x.xyz"))
+    corrupt = str(tmp_path / "c.pcd")
+    IO.write_pcd(corrupt, _cloud(500), "binary_compressed")
+    raw = bytearray(open(corrupt, "rb").read())
+    raw[-40] ^= 0xE0
+    open(corrupt, "wb").write(bytes(raw[:-7]))
+    with pytest.raises(lib.BxError):
+        ing.read_point_cloud(corrupt)
+
+
+def test_lzf_reference_vector():
+    """The LZF token format, pinned on a hand-assembled stream: literal 'abc', then a back reference (length 9, distance 3)."""
+    stream = bytes([2]) + b"abc" + bytes([(7 << 5) | 0, 0, 2])
+    assert IO.lzf_decompress(stream, 12) == b"abcabcabcabc"
+    data = bytes(np.random.default_rng(0).integers(0, 3, 4000, dtype=np.uint8)) + b"\0" * 1000
+    assert IO.lzf_decompress(IO.lzf_compress(data), len(data)) == data
