@@ -30,24 +30,30 @@ def unpack_record(r):
                 scales_used=int(r[16]), model_ms=float(r[17]))
 
 
-def gather_records(local, n_pairs, device=None):
-    """local: float32 [n_local, RECORD] of this rank's pairs -> float32 [n_pairs, RECORD] ordered by pair id on every
-    rank.  One all_gather of equal-sized, -1-padded blocks."""
+def gather_rows(local, n_rows, device=None):
+    """local: [n_local, W] (float32 or float64) rows of this rank, unit id in column 0 -> [n_rows, W] ordered by id on every
+    rank.  ONE all_gather of equal-sized, -1-padded blocks (RCCL over xGMI with backend nccl; gloo on CPU)."""
     import torch
     import torch.distributed as dist
-    local = np.asarray(local, np.float32).reshape(-1, RECORD)
+    local = np.asarray(local)
+    assert local.ndim == 2 and local.dtype in (np.float32, np.float64)
+    W = local.shape[1]
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        out = local[np.argsort(local[:, 0], kind="stable")]
-        return out
+        return local[np.argsort(local[:, 0], kind="stable")]
     world = dist.get_world_size()
-    per = (n_pairs + world - 1) // world
-    buf = np.full((per, RECORD), -1.0, np.float32)
+    per = (n_rows + world - 1) // world
+    buf = np.full((per, W), -1.0, local.dtype)
     buf[:len(local)] = local
     t = torch.from_numpy(buf)
     if device is not None:
         t = t.to(device)
-    out = torch.empty((world * per, RECORD), dtype=torch.float32, device=t.device)
+    out = torch.empty((world * per, W), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t)
     out = out.cpu().numpy()
     out = out[out[:, 0] >= 0]
     return out[np.argsort(out[:, 0], kind="stable")]
+
+
+def gather_records(local, n_pairs, device=None):
+    """local: float32 [n_local, RECORD] of this rank's pairs -> float32 [n_pairs, RECORD] ordered by pair id on every rank."""
+    return gather_rows(np.asarray(local, np.float32).reshape(-1, RECORD), n_pairs, device)
