@@ -1,0 +1,72 @@
+"""End-to-end pipeline on the GPU (buffer-x_amd/harness.py): files -> prefetch -> GPU pre-processing -> pairs in flight -> metrics,
+against the same steps made one by one, synchronously, with the same NumPy seed (bit-identical poses), and the evaluation rows."""
+import numpy as np
+import pytest
+
+from oracle import io_oracle as IO
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(bx):
+    cfg = bx.make_cfg("3DMatch")
+    cfg.patch.num_fps, cfg.patch.num_points_per_patch, cfg.patch.num_scales = 256, 128, 2
+    cfg.patch.search_radius_thresholds = [5, 2]
+    cfg.patch.num_points_radius_estimate = 256
+    cfg.test.pose_refine = True
+    return cfg
+
+
+def test_runner_matches_step_by_step(tmp_path, bx, packed):
+    import torch
+    from bufferx_amd import evaluate, harness, ingest, lib
+    from bufferx_amd.preprocess import Preprocessor
+    rng = np.random.default_rng(3)
+    pairs = []
+    for i in range(4):
+        p = bx.synth.make_pair(20 + i, "indoor", n_target=9000, jitter=0.0)
+        # raw scans: every surface point several times with millimetre jitter, so that the first down-sampling has work to do
+        raw = [np.concatenate([c + rng.normal(0, 0.002, c.shape) for _ in range(3)]).astype(np.float32) for c in (p["src"], p["tgt"])]
+        fs, ft = str(tmp_path / f"s{i}.ply"), str(tmp_path / (f"t{i}.pcd" if i % 2 else f"t{i}.ply"))
+        IO.write_ply(fs, raw[0])
+        (IO.write_pcd(ft, raw[1], "binary_compressed") if i % 2 else IO.write_ply(ft, raw[1], "binary_big_endian"))
+        pairs.append(dict(src_path=fs, tgt_path=ft, relt_pose=p["T_gt"]))
+    cfg = _cfg(bx)
+
+    np.random.seed(11)
+    run = harness.Runner(cfg, packed, device=0, inflight=3, max_raw_points=40000, max_points=40000)
+    try:
+        rows, poses = run.run(pairs)
+    finally:
+        run.close()
+    assert rows.shape == (4, evaluate.STATE_W) and list(rows[:, 0]) == [0, 1, 2, 3]
+
+    # the same steps one by one
+    np.random.seed(11)
+    ctx = lib.Context(cfg, max_points=40000, device=0, packed_weights=packed)
+    pre = Preprocessor(ctx, 40000)
+    try:
+        for i, p in enumerate(pairs):
+            src_raw, tgt_raw = ingest.read_point_cloud(p["src_path"]), ingest.read_point_cloud(p["tgt_path"])
+            vs, _, _ = pre.sphericity_based_voxel_analysis(src_raw, tgt_raw)
+            src, tgt = pre.voxel_down_sample(src_raw, vs), pre.voxel_down_sample(tgt_raw, vs)
+            src = ctx.permute(src, np.random.permutation(src.shape[0]).astype(np.int32))
+            tgt = ctx.permute(tgt, np.random.permutation(tgt.shape[0]).astype(np.int32))
+            counts = [pre.voxel_down_sample(x, cfg.data.voxel_size_0).shape[0] for x in (src, tgt)]
+            for m in counts:
+                np.random.permutation(m)
+            ps, pt = [], []
+            for _ in range(2):
+                ps.append(np.random.choice(src.shape[0], src.shape[0], replace=False).astype(np.int32))
+                pt.append(np.random.choice(tgt.shape[0], tgt.shape[0], replace=False).astype(np.int32))
+            seed = int(np.random.randint(0, 2**31 - 1))
+            res = ctx.register_pair(src, tgt, cfg.patch.is_aligned_to_global_z, np.stack(ps), np.stack(pt), seed)
+            pose = np.array(res.pose, np.float64).reshape(4, 4).astype(np.float32)
+            assert np.array_equal(pose, poses[i]), i
+            assert rows[i, 4] == res.num_inliers and rows[i, 5] == res.num_mutual and rows[i, 7] == res.scales_used
+            assert rows[i, 2] == evaluate.compute_rte(pose, np.asarray(p["relt_pose"], np.float64))
+            assert np.array_equal(evaluate.state_pose(rows[i]), pose)
+    finally:
+        ctx.close()
+    s = evaluate.summarize(evaluate.states_matrix(rows))
+    assert 0.0 <= s["recall"] <= 1.0 and s["average_times"].shape == (5,)
