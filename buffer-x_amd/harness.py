@@ -10,9 +10,14 @@ while up to `inflight` earlier pairs occupy the GPU, and nothing on the registra
 NumPy's global RNG is consumed by the same calls, in the same order, as dataset/threedmatch.py + models/patch_embedder.py make
 them (analysis subsamples, shuffle of both clouds, the two shuffles of the second down-sampling, the per-scale permutations), so
 a seeded run replays the reference's random choices; the RANSAC seed is one extra draw (Open3D's RANSAC is unseeded upstream)."""
+import os
 import time
 
 import numpy as np
+
+# the loop drives C registration streams + a preparation stream + the prefetcher's copy stream: with HIP's default of 4 hardware
+# queues two of them would share a queue and the preparation would wait behind a whole pair (read at HIP initialisation)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from . import evaluate, ingest, lib
 from .preprocess import Preprocessor
@@ -27,8 +32,24 @@ class Runner:
         self.ctxs = [lib.Context(cfg, max_points=self.max_points, device=self.device, packed_weights=packed_weights) for _ in range(self.C)]
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.C)]
         self.results = [c.new_result() for c in self.ctxs]
-        self.prep_stream = torch.cuda.Stream(device=self.device)
-        self.pre = Preprocessor(self.ctxs[0], max_raw_points)       # bx_pre_* has its own workspace inside the context
+        # high priority: the preparation kernels are tiny and the host waits for three of their results per pair; they must not
+        # queue behind the convolution kernels of the pairs in flight
+        self.prep_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get('BX_PREP_PRIO', '0')))
+        self._pin, self._pin_ev = {}, {}
+        self.timers = {k: 0.0 for k in ("wait_prefetch", "voxel_analysis", "down_sample", "shuffle", "second_sampling_rng", "perm_rng",
+                                        "perm_upload", "harvest_wait", "enqueue")}   # host seconds, accumulated over run()
+        self.pre = Preprocessor(self.ctxs[0], max_raw_points, upload=self._upload)   # bx_pre_* has its own workspace in the context
+        # every device buffer of the loop is allocated ONCE: an allocation under load costs a hipMalloc, i.e. a device-wide wait.
+        # Pair i uses buffer set i % (C + 1): the C pairs before it may still be in flight.
+        dev = f"cuda:{self.device}"
+        S = int(cfg.patch.num_scales)
+        f32, i32 = torch.float32, torch.int32
+        self.sets = [dict(src=torch.empty((self.max_points, 3), dtype=f32, device=dev), tgt=torch.empty((self.max_points, 3), dtype=f32, device=dev),
+                          perm_s=torch.empty(S * self.max_points, dtype=i32, device=dev), perm_t=torch.empty(S * self.max_points, dtype=i32, device=dev))
+                     for _ in range(self.C + 1)]
+        self.scratch = dict(fds_s=torch.empty((max_raw_points, 3), dtype=f32, device=dev), fds_t=torch.empty((max_raw_points, 3), dtype=f32, device=dev),
+                            sds_s=torch.empty((self.max_points, 3), dtype=f32, device=dev), sds_t=torch.empty((self.max_points, 3), dtype=f32, device=dev))
+        self._devbuf = {}
         self.pf = ingest.Prefetcher(device=self.device, slots=self.C + 2, max_points=max_raw_points)
 
     def close(self):
@@ -36,34 +57,62 @@ class Runner:
         for c in self.ctxs:
             c.close()
 
+    def _upload(self, key, arr, into=None):
+        """host array -> device through a reusable pinned staging buffer (a pageable source makes the copy synchronous)"""
+        t = self.torch
+        arr = np.ascontiguousarray(arr)
+        buf = self._pin.get(key)
+        if buf is None or buf.numel() < arr.size or buf.dtype != t.from_numpy(arr).dtype:
+            buf = t.empty(max(arr.size, 1), dtype=t.from_numpy(arr).dtype).pin_memory()
+            self._pin[key] = buf
+        else:
+            self._pin_ev[key].synchronize()              # the previous copy out of this buffer has completed
+        view = buf[:arr.size].view(arr.shape) if arr.size else buf[:0]
+        view.copy_(t.from_numpy(arr))
+        dbuf = self._devbuf.get(key) if into is None else into
+        if dbuf is None or dbuf.numel() < arr.size:
+            dbuf = t.empty(max(arr.size, 1) * 2, dtype=buf.dtype, device=f"cuda:{self.device}")   # grows geometrically, rarely
+            self._devbuf[key] = dbuf
+        dev = dbuf[:arr.size].view(arr.shape) if arr.size else dbuf[:0]
+        dev.copy_(view, non_blocking=True)
+        ev = t.cuda.Event()
+        ev.record(t.cuda.current_stream(self.device))
+        self._pin_ev[key] = ev
+        return dev
+
     # ------------------------------------------------------------------------------------------ per-pair preparation
-    def _prepare(self, ticket, voxel_size, replay_rng):
+    def _prepare(self, ticket, voxel_size, replay_rng, bufs):
         """dataset/threedmatch.py:75-135 for the test split, on the GPU.  Returns (src, tgt, aligned_z, voxel_size, sphericity)."""
         cfg, pre, t = self.cfg, self.pre, self.torch
+        tm = self.timers
+        t0 = time.perf_counter()
         src_raw, tgt_raw = self.pf.wait(ticket)
+        tm["wait_prefetch"] += time.perf_counter() - t0; t0 = time.perf_counter()
         sphericity = 0.0
         if voxel_size is None:
             voxel_size, sphericity, _ = pre.sphericity_based_voxel_analysis(src_raw, tgt_raw)
-        src = pre.voxel_down_sample(src_raw, voxel_size)
-        tgt = pre.voxel_down_sample(tgt_raw, voxel_size)
+        tm["voxel_analysis"] += time.perf_counter() - t0; t0 = time.perf_counter()
+        sc = self.scratch
+        src, tgt = pre.voxel_down_sample_many([src_raw, tgt_raw], voxel_size, outs=[sc["fds_s"], sc["fds_t"]])
         self.pf.release(ticket)
+        tm["down_sample"] += time.perf_counter() - t0; t0 = time.perf_counter()
         if src.shape[0] > self.max_points or tgt.shape[0] > self.max_points:
             raise lib.BxError(f"down-sampled cloud of {max(src.shape[0], tgt.shape[0])} points exceeds max_points={self.max_points}")
         # np.random.shuffle(pts) == pts[np.random.permutation(len(pts))], same RNG consumption
-        ps = t.from_numpy(np.random.permutation(src.shape[0]).astype(np.int32))
-        src = self.ctxs[0].permute(src, ps)
-        pt = t.from_numpy(np.random.permutation(tgt.shape[0]).astype(np.int32))
-        tgt = self.ctxs[0].permute(tgt, pt)
+        src = self.ctxs[0].permute(src, self._upload("shuf_s", np.random.permutation(src.shape[0]).astype(np.int32)), out=bufs["src"])
+        tgt = self.ctxs[0].permute(tgt, self._upload("shuf_t", np.random.permutation(tgt.shape[0]).astype(np.int32)), out=bufs["tgt"])
+        tm["shuffle"] += time.perf_counter() - t0; t0 = time.perf_counter()
         if replay_rng:
             # the loader's second down-sampling only feeds training, but its shuffles (and the max_numPts subsample) advance the RNG
             vs0 = float(cfg.data.voxel_size_0)
             max_n = int(cfg.data.get("max_numPts", 30000))
-            counts = [int(pre.voxel_down_sample(x, vs0).shape[0]) for x in (src, tgt)]
+            counts = [int(x.shape[0]) for x in pre.voxel_down_sample_many([src, tgt], vs0, outs=[sc["sds_s"], sc["sds_t"]])]
             for m in counts:
                 np.random.permutation(m)
             for m in counts:
                 if m > max_n:
                     np.random.choice(range(m), max_n, replace=False)
+        tm["second_sampling_rng"] += time.perf_counter() - t0
         return src, tgt, bool(cfg.patch.is_aligned_to_global_z), voxel_size, sphericity
 
     # ------------------------------------------------------------------------------------------ the loop
@@ -98,31 +147,36 @@ class Runner:
         for i in range(n):
             t0 = time.perf_counter()
             with t.cuda.stream(self.prep_stream):
-                src, tgt, aligned, _, _ = self._prepare(tickets[i], voxel_size, replay_rng)
+                bufs = self.sets[i % (C + 1)]
+                src, tgt, aligned, _, _ = self._prepare(tickets[i], voxel_size, replay_rng, bufs)
+                tq = time.perf_counter()
                 perm_s, perm_t = [], []
                 for _ in range(S):        # models/patch_embedder.py:96, order scale0-src, scale0-tgt, scale1-src, ...
                     perm_s.append(np.random.choice(src.shape[0], src.shape[0], replace=False).astype(np.int32))
                     perm_t.append(np.random.choice(tgt.shape[0], tgt.shape[0], replace=False).astype(np.int32))
                 seed = int(np.random.randint(0, 2**31 - 1))
-                d_ps = t.from_numpy(np.stack(perm_s)).to(f"cuda:{self.device}", non_blocking=True)
-                d_pt = t.from_numpy(np.stack(perm_t)).to(f"cuda:{self.device}", non_blocking=True)
+                self.timers["perm_rng"] += time.perf_counter() - tq; tq = time.perf_counter()
+                d_ps = self._upload("perm_s", np.stack(perm_s), into=bufs["perm_s"])
+                d_pt = self._upload("perm_t", np.stack(perm_t), into=bufs["perm_t"])
+                self.timers["perm_upload"] += time.perf_counter() - tq
                 ready = t.cuda.Event()
                 ready.record(self.prep_stream)
             if i + depth < n:
                 tickets.append(self.pf.submit(pairs[i + depth]["src_path"], pairs[i + depth]["tgt_path"]))
             data_s = time.perf_counter() - t0
             c = i % C
+            tq = time.perf_counter()
             harvest(c)
+            self.timers["harvest_wait"] += time.perf_counter() - tq; tq = time.perf_counter()
             st = self.streams[c]
             st.wait_event(ready)
-            for x in (src, tgt, d_ps, d_pt):
-                x.record_stream(st)
             with t.cuda.stream(st):
                 a, b = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
                 a.record(st)
                 self.ctxs[c].register_pair_async(src, tgt, aligned, d_ps, d_pt, seed, self.results[c])
                 b.record(st)
             pending[c] = (i, a, b, data_s)
+            self.timers["enqueue"] += time.perf_counter() - tq
         for c in range(C):
             harvest(c)
         return np.stack(rows) if n else np.zeros((0, evaluate.STATE_W)), poses

@@ -248,10 +248,10 @@ class Context:
              "bx_radius")
         return out
 
-    def permute(self, pts, perm):
+    def permute(self, pts, perm, out=None):
         t = self.torch
         pts, perm = self._dev(pts, t.float32), self._dev(perm, t.int32)
-        out = self._empty(tuple(pts.shape), t.float32)
+        out = self._empty(tuple(pts.shape), t.float32) if out is None else out[:pts.shape[0]]
         _chk(self.lib.bx_permute(self.handle, self._stream(), self._p(pts), self._p(perm), C.c_int32(pts.shape[0]),
                                  self._p(out)), "bx_permute")
         return out
@@ -272,22 +272,23 @@ class Context:
     def pre_reserve(self, max_points):
         _chk(self.lib.bx_pre_reserve(self.handle, C.c_int64(int(max_points))), "bx_pre_reserve")
 
-    def pre_voxel_downsample(self, pts, voxel_size):
-        """-> (out float32 [n,3] device tensor (first m rows valid), count device int32[2] = {m, status})"""
+    def pre_voxel_downsample(self, pts, voxel_size, out=None, cnt=None):
+        """-> (out float32 [n,3] device tensor (first m rows valid), count device int32[2] = {m, status}); `out` (>= n rows) and
+        `cnt` may be caller-owned buffers (no allocation on the hot loop)"""
         t = self.torch
         pts = self._dev(pts, t.float32)
         n = pts.shape[0]
-        out = self._empty((n, 3), t.float32)
-        cnt = self._empty((2,), t.int32)
+        out = self._empty((n, 3), t.float32) if out is None else out
+        cnt = self._empty((2,), t.int32) if cnt is None else cnt
         _chk(self.lib.bx_pre_voxel_downsample(self.handle, self._stream(), self._p(pts), C.c_int32(n), C.c_double(float(voxel_size)),
                                               self._p(out), self._p(cnt)), "bx_pre_voxel_downsample")
         return out, cnt
 
-    def pre_pca(self, pts, sample_idx):
+    def pre_pca(self, pts, sample_idx, out=None):
         t = self.torch
         pts = self._dev(pts, t.float32)
         idx = self._dev(sample_idx, t.int32)
-        out = self._empty((17,), t.float64)
+        out = self._empty((17,), t.float64) if out is None else out
         _chk(self.lib.bx_pre_pca(self.handle, self._stream(), self._p(pts), C.c_int32(pts.shape[0]), self._p(idx),
                                  C.c_int32(idx.shape[0]), self._p(out)), "bx_pre_pca")
         return out

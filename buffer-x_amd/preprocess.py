@@ -14,14 +14,25 @@ from . import lib as _lib
 
 
 class Preprocessor:
-    def __init__(self, ctx, max_points):
+    def __init__(self, ctx, max_points, upload=None):
+        """upload: optional callable (key, numpy array) -> device tensor used for the subsample indices (harness: pinned staging +
+        persistent device buffers); the default lets torch allocate."""
         self.ctx = ctx
+        self.upload = upload
         ctx.pre_reserve(max_points)
+        t = ctx.torch
+        self._st = t.empty((2, 17), dtype=t.float64, device=f"cuda:{ctx.device}")       # PCA statistics of src / tgt
+        self._cnt = t.empty((8, 2), dtype=t.int32, device=f"cuda:{ctx.device}")          # voxel counts of up to 8 clouds
 
-    def _pca(self, pts_dev, num_points):
+    def _pca_launch(self, pts_dev, num_points, slot):
         idx = np.random.choice(num_points, size=int(num_points / 10), replace=False).astype(np.int32)
-        st = self.ctx.pre_pca(pts_dev, idx).cpu().numpy()
-        ev, comp, mean = st[0:3], st[3:12].reshape(3, 3), st[12:15]
+        if self.upload is not None:
+            idx = self.upload(f"pca_idx{slot}", idx)
+        return self.ctx.pre_pca(pts_dev, idx, out=self._st[slot])   # device float64 [17]; nothing waits for it yet
+
+    @staticmethod
+    def _pca_stats(st):
+        ev, comp = st[0:3], st[3:12].reshape(3, 3)
         l1, l2, l3 = sorted(ev, reverse=True)
         sphericity = l3 / l1
         z = comp[-1] / np.linalg.norm(comp[-1])
@@ -33,8 +44,11 @@ class Preprocessor:
         t = self.ctx.torch
         src = self.ctx._dev(src_pts, t.float32)
         tgt = self.ctx._dev(tgt_pts, t.float32)
-        s_src, a_src, c_src, zr_src = self._pca(src, src.shape[0])
-        s_tgt, a_tgt, c_tgt, zr_tgt = self._pca(tgt, tgt.shape[0])
+        self._pca_launch(src, src.shape[0], 0)
+        self._pca_launch(tgt, tgt.shape[0], 1)
+        st = self._st.cpu().numpy()                                                     # ONE host sync
+        s_src, a_src, c_src, zr_src = self._pca_stats(st[0])
+        s_tgt, a_tgt, c_tgt, zr_tgt = self._pca_stats(st[1])
         if src.shape[0] > tgt.shape[0]:
             sphericity, z_range = s_src, zr_src
         else:
@@ -53,3 +67,13 @@ class Preprocessor:
         if status:
             raise _lib.BxError("voxel size too small for the extent of the cloud (more than 2^21 voxels along an axis)")
         return out[:m]
+
+    def voxel_down_sample_many(self, clouds, voxel_size, outs=None):
+        """Several (<= 8) clouds, ONE host synchronisation for all the voxel counts -> list of float32 device tensors [m_i,3];
+        outs: optional caller-owned output buffers (>= len(cloud) rows each)."""
+        res = [self.ctx.pre_voxel_downsample(c, voxel_size, out=None if outs is None else outs[k], cnt=self._cnt[k])
+               for k, c in enumerate(clouds)]
+        cnt = self._cnt[:len(clouds)].cpu().numpy()
+        if cnt[:, 1].any():
+            raise _lib.BxError("voxel size too small for the extent of the cloud (more than 2^21 voxels along an axis)")
+        return [r[0][:int(m)] for r, m in zip(res, cnt[:, 0])]
