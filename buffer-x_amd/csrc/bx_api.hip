@@ -608,6 +608,14 @@ int bx_pre_voxel_downsample(bx_ctx* c, void* stream, const float* pts, int32_t n
     return bxk_pre_voxel_downsample(c, (hipStream_t)stream, pts, n, voxel_size, out, count_out);
 }
 
+int bx_random_perm(bx_ctx* c, void* stream, int32_t n, uint64_t seed, int32_t* out)
+{
+    int rc;
+    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    if (!out || n < 0 || n > (1 << 30)) { bx_set_error("bx_random_perm: bad argument"); return BX_ERR_ARG; }
+    return bxk_random_perm((hipStream_t)stream, n, seed, out);
+}
+
 int bx_pre_pca(bx_ctx* c, void* stream, const float* pts, int32_t n, const int32_t* sample_idx, int32_t ns, double* out17)
 {
     int rc;

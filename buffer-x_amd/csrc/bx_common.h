@@ -178,6 +178,7 @@ int bxk_ransac(bx_ctx* c, hipStream_t s, const float* ss, const float* tt, const
 int bxk_pre_reserve(bx_ctx* c, int64_t max_points);
 void bxk_pre_release(bx_ctx* c);
 int bxk_pre_voxel_downsample(bx_ctx* c, hipStream_t s, const float* pts, int n, double voxel_size, float* out, int32_t* count_out);
+int bxk_random_perm(hipStream_t s, int n, uint64_t seed, int32_t* out);
 int bxk_pre_pca(bx_ctx* c, hipStream_t s, const float* pts, int n, const int32_t* sample_idx, int ns, double* out17);
 int bxk_refine(bx_ctx* c, hipStream_t s, const float* ss, const float* tt, const int32_t* M_dev, int max_M, float* T_io,
                int32_t* iters_out);

@@ -216,6 +216,35 @@ __global__ __launch_bounds__(256) void pre_compact_kernel(int n, const PreGrid* 
     out[o] = cen[(size_t)i * 3]; out[o + 1] = cen[(size_t)i * 3 + 1]; out[o + 2] = cen[(size_t)i * 3 + 2];
 }
 
+// ---------------------------------------------------------------------------------------------- random permutation
+// A permutation of [0, n) computed element by element, no sort and no host RNG: a 4-round Feistel network over 2w bits
+// (2^(2w) >= n, w = ceil(log2(n) / 2)) keyed by mix64(seed, round, half) is a bijection of [0, 2^(2w)); walking its cycle until the
+// value falls below n ("cycle walking") restricts it to a bijection of [0, n).  2^(2w) < 4n, so a lane walks < 4 steps on average.
+// It stands in for np.random.choice(N, N, replace=False) (models/patch_embedder.py:96) / np.random.shuffle
+// (dataset/threedmatch.py:99,109) when the reference's exact legacy-NumPy stream is not required: any permutation gives "the
+// first P neighbours in a random order"; the host draws cost ~20 ms per pair, this costs microseconds.
+__host__ __device__ inline uint32_t pre_feistel(uint32_t x, int w, uint64_t seed)
+{
+    const uint32_t mask = (1u << w) - 1u;
+    uint32_t L = x >> w, R = x & mask;
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t f = (uint32_t)bx_mix64(seed, ((uint64_t)r << 32) | R) & mask;
+        const uint32_t nl = R;
+        R = L ^ f;
+        L = nl;
+    }
+    return (L << w) | R;
+}
+
+__global__ __launch_bounds__(256) void random_perm_kernel(int n, int w, uint64_t seed, int32_t* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t x = pre_feistel((uint32_t)i, w, seed);
+    while (x >= (uint32_t)n) x = pre_feistel(x, w, seed);
+    out[i] = (int32_t)x;
+}
+
 // ---------------------------------------------------------------------------------------------- PCA
 constexpr int PCA_BLOCKS = 64;
 
@@ -414,6 +443,16 @@ int bxk_pre_pca(bx_ctx* c, hipStream_t s, const float* pts, int n, const int32_t
     const int nb = (n + 255) / 256;
     hipLaunchKernelGGL(pca_zrange_kernel, dim3(nb < 512 ? nb : 512), dim3(256), 0, s, pts, n, out17, w->zr);
     hipLaunchKernelGGL(pca_zfinish_kernel, dim3(1), dim3(64), 0, s, w->zr, out17);
+    BX_LAUNCH_CHECK();
+    return BX_OK;
+}
+
+int bxk_random_perm(hipStream_t s, int n, uint64_t seed, int32_t* out)
+{
+    if (n < 1) return BX_OK;
+    int w = 1;
+    while (((int64_t)1 << (2 * w)) < (int64_t)n) ++w;
+    hipLaunchKernelGGL(random_perm_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, w, seed, out);
     BX_LAUNCH_CHECK();
     return BX_OK;
 }

@@ -17,16 +17,20 @@ import numpy as np
 
 # the loop drives C registration streams + a preparation stream + the prefetcher's copy stream: with HIP's default of 4 hardware
 # queues two of them would share a queue and the preparation would wait behind a whole pair (read at HIP initialisation)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 from . import evaluate, ingest, lib
 from .preprocess import Preprocessor
 
 
 class Runner:
-    def __init__(self, cfg, packed_weights, device=0, inflight=3, max_raw_points=400000, max_points=80000):
+    def __init__(self, cfg, packed_weights, device=0, inflight=3, max_raw_points=400000, max_points=80000, rng="reference"):
+        """rng: "reference" replays the loaders' legacy-NumPy draws call by call (about 20 ms of host time per pair); "device"
+        computes every subsample / shuffle / permutation on the GPU (bx_random_perm, seeded from ONE np.random draw per pair)."""
         import torch
         self.torch, self.cfg, self.device = torch, cfg, int(device)
+        assert rng in ("reference", "device")
+        self.rng = rng
         self.C = max(1, int(inflight))
         self.max_points = int(max_points)
         self.ctxs = [lib.Context(cfg, max_points=self.max_points, device=self.device, packed_weights=packed_weights) for _ in range(self.C)]
@@ -48,7 +52,8 @@ class Runner:
                           perm_s=torch.empty(S * self.max_points, dtype=i32, device=dev), perm_t=torch.empty(S * self.max_points, dtype=i32, device=dev))
                      for _ in range(self.C + 1)]
         self.scratch = dict(fds_s=torch.empty((max_raw_points, 3), dtype=f32, device=dev), fds_t=torch.empty((max_raw_points, 3), dtype=f32, device=dev),
-                            sds_s=torch.empty((self.max_points, 3), dtype=f32, device=dev), sds_t=torch.empty((self.max_points, 3), dtype=f32, device=dev))
+                            sds_s=torch.empty((self.max_points, 3), dtype=f32, device=dev), sds_t=torch.empty((self.max_points, 3), dtype=f32, device=dev),
+                            idx_s=torch.empty(max_raw_points, dtype=i32, device=dev), idx_t=torch.empty(max_raw_points, dtype=i32, device=dev))
         self._devbuf = {}
         self.pf = ingest.Prefetcher(device=self.device, slots=self.C + 2, max_points=max_raw_points)
 
@@ -89,16 +94,35 @@ class Runner:
         src_raw, tgt_raw = self.pf.wait(ticket)
         tm["wait_prefetch"] += time.perf_counter() - t0; t0 = time.perf_counter()
         sphericity = 0.0
-        if voxel_size is None:
-            voxel_size, sphericity, _ = pre.sphericity_based_voxel_analysis(src_raw, tgt_raw)
-        tm["voxel_analysis"] += time.perf_counter() - t0; t0 = time.perf_counter()
         sc = self.scratch
+        c0 = self.ctxs[0]
+        dev_rng = self.rng == "device"
+        if dev_rng:
+            base = int(np.random.randint(0, 2**31 - 1)) << 8          # the ONE host draw of this pair; +k = its k-th device stream
+        if voxel_size is None:
+            sidx = None
+            if dev_rng:     # a 10 % subsample without replacement = the head of a random permutation
+                ns_, nt_ = src_raw.shape[0], tgt_raw.shape[0]
+                sidx = (c0.random_perm(ns_, base + 0, out=sc["idx_s"])[:ns_ // 10], c0.random_perm(nt_, base + 1, out=sc["idx_t"])[:nt_ // 10])
+            voxel_size, sphericity, _ = pre.sphericity_based_voxel_analysis(src_raw, tgt_raw, sample_idx=sidx)
+        tm["voxel_analysis"] += time.perf_counter() - t0; t0 = time.perf_counter()
         src, tgt = pre.voxel_down_sample_many([src_raw, tgt_raw], voxel_size, outs=[sc["fds_s"], sc["fds_t"]])
         self.pf.release(ticket)
         tm["down_sample"] += time.perf_counter() - t0; t0 = time.perf_counter()
         if src.shape[0] > self.max_points or tgt.shape[0] > self.max_points:
             raise lib.BxError(f"down-sampled cloud of {max(src.shape[0], tgt.shape[0])} points exceeds max_points={self.max_points}")
         # np.random.shuffle(pts) == pts[np.random.permutation(len(pts))], same RNG consumption
+        if dev_rng:
+            src = c0.permute(src, c0.random_perm(src.shape[0], base + 2, out=sc["idx_s"]), out=bufs["src"])
+            tgt = c0.permute(tgt, c0.random_perm(tgt.shape[0], base + 3, out=sc["idx_t"]), out=bufs["tgt"])
+            S = int(cfg.patch.num_scales)
+            ns_, nt_ = src.shape[0], tgt.shape[0]
+            for k in range(S):      # per-scale permutations straight into this pair's buffers
+                c0.random_perm(ns_, base + 4 + 2 * k, out=bufs["perm_s"][k * ns_:(k + 1) * ns_])
+                c0.random_perm(nt_, base + 5 + 2 * k, out=bufs["perm_t"][k * nt_:(k + 1) * nt_])
+            self._dev_perms = (bufs["perm_s"][:S * ns_].view(S, ns_), bufs["perm_t"][:S * nt_].view(S, nt_), base + 255)
+            tm["shuffle"] += time.perf_counter() - t0
+            return src, tgt, bool(cfg.patch.is_aligned_to_global_z), voxel_size, sphericity
         src = self.ctxs[0].permute(src, self._upload("shuf_s", np.random.permutation(src.shape[0]).astype(np.int32)), out=bufs["src"])
         tgt = self.ctxs[0].permute(tgt, self._upload("shuf_t", np.random.permutation(tgt.shape[0]).astype(np.int32)), out=bufs["tgt"])
         tm["shuffle"] += time.perf_counter() - t0; t0 = time.perf_counter()
@@ -150,15 +174,18 @@ class Runner:
                 bufs = self.sets[i % (C + 1)]
                 src, tgt, aligned, _, _ = self._prepare(tickets[i], voxel_size, replay_rng, bufs)
                 tq = time.perf_counter()
-                perm_s, perm_t = [], []
-                for _ in range(S):        # models/patch_embedder.py:96, order scale0-src, scale0-tgt, scale1-src, ...
-                    perm_s.append(np.random.choice(src.shape[0], src.shape[0], replace=False).astype(np.int32))
-                    perm_t.append(np.random.choice(tgt.shape[0], tgt.shape[0], replace=False).astype(np.int32))
-                seed = int(np.random.randint(0, 2**31 - 1))
-                self.timers["perm_rng"] += time.perf_counter() - tq; tq = time.perf_counter()
-                d_ps = self._upload("perm_s", np.stack(perm_s), into=bufs["perm_s"])
-                d_pt = self._upload("perm_t", np.stack(perm_t), into=bufs["perm_t"])
-                self.timers["perm_upload"] += time.perf_counter() - tq
+                if self.rng == "device":
+                    d_ps, d_pt, seed = self._dev_perms
+                else:
+                    perm_s, perm_t = [], []
+                    for _ in range(S):        # models/patch_embedder.py:96, order scale0-src, scale0-tgt, scale1-src, ...
+                        perm_s.append(np.random.choice(src.shape[0], src.shape[0], replace=False).astype(np.int32))
+                        perm_t.append(np.random.choice(tgt.shape[0], tgt.shape[0], replace=False).astype(np.int32))
+                    seed = int(np.random.randint(0, 2**31 - 1))
+                    self.timers["perm_rng"] += time.perf_counter() - tq; tq = time.perf_counter()
+                    d_ps = self._upload("perm_s", np.stack(perm_s), into=bufs["perm_s"])
+                    d_pt = self._upload("perm_t", np.stack(perm_t), into=bufs["perm_t"])
+                    self.timers["perm_upload"] += time.perf_counter() - tq
                 ready = t.cuda.Event()
                 ready.record(self.prep_stream)
             if i + depth < n:

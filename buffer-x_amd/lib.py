@@ -43,7 +43,7 @@ EXPORTS = ["bx_create", "bx_destroy", "bx_last_error", "bx_load_weights", "bx_wo
            "bx_profile_enable", "bx_profile_read", "bx_debug_read",
            "bx_fps", "bx_radius", "bx_permute", "bx_ball_group", "bx_patch_features", "bx_desc_net", "bx_conv_layer",
            "bx_mutual", "bx_pose_net", "bx_hypotheses", "bx_consensus", "bx_ransac", "bx_refine",
-           "bx_pre_reserve", "bx_pre_voxel_downsample", "bx_pre_pca",
+           "bx_pre_reserve", "bx_pre_voxel_downsample", "bx_pre_pca", "bx_random_perm",
            "bx_lane_create", "bx_lane_destroy", "bx_attach_lane",
            "bx_io_probe", "bx_io_read_xyz", "bx_prefetch_create", "bx_prefetch_submit", "bx_prefetch_wait", "bx_prefetch_release",
            "bx_prefetch_destroy"]
@@ -283,6 +283,13 @@ class Context:
         _chk(self.lib.bx_pre_voxel_downsample(self.handle, self._stream(), self._p(pts), C.c_int32(n), C.c_double(float(voxel_size)),
                                               self._p(out), self._p(cnt)), "bx_pre_voxel_downsample")
         return out, cnt
+
+    def random_perm(self, n, seed, out=None):
+        """device int32 [n]: permutation of range(n) determined by seed (no host RNG, no H2D copy)"""
+        out = self._empty((int(n),), self.torch.int32) if out is None else out[:int(n)]
+        _chk(self.lib.bx_random_perm(self.handle, self._stream(), C.c_int32(int(n)), C.c_uint64(int(seed) & (2**64 - 1)), self._p(out)),
+             "bx_random_perm")
+        return out
 
     def pre_pca(self, pts, sample_idx, out=None):
         t = self.torch

@@ -24,10 +24,11 @@ class Preprocessor:
         self._st = t.empty((2, 17), dtype=t.float64, device=f"cuda:{ctx.device}")       # PCA statistics of src / tgt
         self._cnt = t.empty((8, 2), dtype=t.int32, device=f"cuda:{ctx.device}")          # voxel counts of up to 8 clouds
 
-    def _pca_launch(self, pts_dev, num_points, slot):
-        idx = np.random.choice(num_points, size=int(num_points / 10), replace=False).astype(np.int32)
-        if self.upload is not None:
-            idx = self.upload(f"pca_idx{slot}", idx)
+    def _pca_launch(self, pts_dev, num_points, slot, idx=None):
+        if idx is None:
+            idx = np.random.choice(num_points, size=int(num_points / 10), replace=False).astype(np.int32)
+            if self.upload is not None:
+                idx = self.upload(f"pca_idx{slot}", idx)
         return self.ctx.pre_pca(pts_dev, idx, out=self._st[slot])   # device float64 [17]; nothing waits for it yet
 
     @staticmethod
@@ -39,13 +40,14 @@ class Preprocessor:
         is_aligned = abs(float(np.dot(z, np.array([0, 0, 1])))) > 0.98
         return sphericity, is_aligned, comp, float(st[16] - st[15])
 
-    def sphericity_based_voxel_analysis(self, src_pts, tgt_pts):
-        """-> (voxel_size, sphericity, is_aligned_to_global_z)   (utils/tools.py:152-198)"""
+    def sphericity_based_voxel_analysis(self, src_pts, tgt_pts, sample_idx=None):
+        """-> (voxel_size, sphericity, is_aligned_to_global_z)   (utils/tools.py:152-198).  sample_idx: optional pair of device
+        int32 tensors, the 10 % subsamples (default: drawn with the reference's np.random.choice calls)"""
         t = self.ctx.torch
         src = self.ctx._dev(src_pts, t.float32)
         tgt = self.ctx._dev(tgt_pts, t.float32)
-        self._pca_launch(src, src.shape[0], 0)
-        self._pca_launch(tgt, tgt.shape[0], 1)
+        self._pca_launch(src, src.shape[0], 0, None if sample_idx is None else sample_idx[0])
+        self._pca_launch(tgt, tgt.shape[0], 1, None if sample_idx is None else sample_idx[1])
         st = self._st.cpu().numpy()                                                     # ONE host sync
         s_src, a_src, c_src, zr_src = self._pca_stats(st[0])
         s_tgt, a_tgt, c_tgt, zr_tgt = self._pca_stats(st[1])

@@ -229,6 +229,11 @@ int bx_pre_reserve(bx_ctx *ctx, int64_t max_points);
 int bx_pre_voxel_downsample(bx_ctx *ctx, void *stream, const float *pts, int32_t n, double voxel_size, float *out,
                             int32_t *count_out);
 int bx_pre_pca(bx_ctx *ctx, void *stream, const float *pts, int32_t n, const int32_t *sample_idx, int32_t ns, double *out17);
+/* bx_random_perm: out[0..n) = a permutation of [0, n) determined by seed, computed on the device (4-round Feistel network keyed by
+ * the library's mix64 + cycle walking; oracle/pre_oracle.py::random_perm).  Stands in for the loaders' / the descriptor's host-side
+ * np.random.shuffle / np.random.choice(N, N, replace=False) (dataset/threedmatch.py:99,109, models/patch_embedder.py:96) when the
+ * reference's exact NumPy stream is not needed; the result of bx_register_pair is defined for ANY permutations it is given. */
+int bx_random_perm(bx_ctx *ctx, void *stream, int32_t n, uint64_t seed, int32_t *out);
 
 /* ---- data ingest in front of the hot path (optional) ----------------------------------------------
  * The reference opens every pair synchronously on the main thread: open3d.io.read_point_cloud for .ply

@@ -82,3 +82,36 @@ def sphericity_based_voxel_analysis(src, tgt, idx_src, idx_tgt):
     zt = pca_tgt[1][-1] / np.linalg.norm(pca_tgt[1][-1])
     same = float(np.dot(zs, zt)) > 0.96
     return round(float(voxel_size), 4), float(sphericity), bool(a_src and a_tgt and same)
+
+
+_M64 = (1 << 64) - 1
+
+
+def _mix64(seed, ctr):
+    """splitmix64 finaliser over seed + golden * (ctr + 1): buffer-x_amd/csrc/bx_common.h::bx_mix64 == oracle/bx_oracle.c::bxo_mix64"""
+    z = (seed + 0x9E3779B97F4A7C15 * (ctr + 1)) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def random_perm(n, seed):
+    """Restatement of bx_random_perm (k_pre.hip): 4-round Feistel over 2w bits + cycle walking.  Not a reference function: the
+    reference draws its permutations from NumPy's global RNG; this is the device-side stand-in, specified here."""
+    w = 1
+    while (1 << (2 * w)) < n:
+        w += 1
+    mask = (1 << w) - 1
+
+    def f(x):
+        L, R = x >> w, x & mask
+        for r in range(4):
+            L, R = R, L ^ (_mix64(seed, (r << 32) | R) & mask)
+        return (L << w) | R
+    out = np.empty(n, np.int32)
+    for i in range(n):
+        x = f(i)
+        while x >= n:
+            x = f(x)
+        out[i] = x
+    return out

@@ -70,3 +70,27 @@ def test_runner_matches_step_by_step(tmp_path, bx, packed):
         ctx.close()
     s = evaluate.summarize(evaluate.states_matrix(rows))
     assert 0.0 <= s["recall"] <= 1.0 and s["average_times"].shape == (5,)
+
+
+def test_runner_device_rng_is_deterministic(tmp_path, bx, packed):
+    """rng="device": subsamples, shuffles and per-scale permutations come from bx_random_perm; one NumPy draw per pair seeds them."""
+    from bufferx_amd import evaluate, harness
+    rng = np.random.default_rng(5)
+    pairs = []
+    for i in range(3):
+        p = bx.synth.make_pair(40 + i, "indoor", n_target=8000, jitter=0.0)
+        raw = [np.concatenate([c + rng.normal(0, 0.002, c.shape) for _ in range(3)]).astype(np.float32) for c in (p["src"], p["tgt"])]
+        fs, ft = str(tmp_path / f"s{i}.ply"), str(tmp_path / f"t{i}.ply")
+        IO.write_ply(fs, raw[0]); IO.write_ply(ft, raw[1])
+        pairs.append(dict(src_path=fs, tgt_path=ft, relt_pose=p["T_gt"]))
+    out = []
+    for _ in range(2):
+        np.random.seed(3)
+        run = harness.Runner(_cfg(bx), packed, device=0, inflight=2, max_raw_points=40000, max_points=40000, rng="device")
+        try:
+            out.append(run.run(pairs))
+        finally:
+            run.close()
+    assert np.array_equal(out[0][0][:, :8], out[1][0][:, :8]) and np.array_equal(out[0][0][:, 13:], out[1][0][:, 13:])
+    assert all(np.array_equal(a, b) for a, b in zip(out[0][1], out[1][1]))
+    assert (out[0][0][:, 5] > 0).all()        # mutual matches were found: the permutations fed real neighbourhoods

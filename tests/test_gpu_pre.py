@@ -87,3 +87,15 @@ def test_pca_and_analysis_match_reference(pctx, golden_dir, name):
     # and the down-sampling at that voxel size
     ds = pre.voxel_down_sample(g["src"], vs)
     assert np.array_equal(ds.cpu().numpy(), PO.voxel_down_sample(g["src"], vs))
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 64, 1000, 4097, 65536])
+def test_random_perm_matches_oracle(pctx, n):
+    from oracle import pre_oracle as PO
+    for seed in (0, 12345678901234567):
+        got = pctx.random_perm(n, seed).cpu().numpy()
+        if n <= 4097:
+            assert np.array_equal(got, PO.random_perm(n, seed))
+        assert np.array_equal(np.sort(got), np.arange(n))
+    a, b = pctx.random_perm(max(n, 2), 1).cpu().numpy(), pctx.random_perm(max(n, 2), 2).cpu().numpy()
+    assert n < 64 or not np.array_equal(a, b)

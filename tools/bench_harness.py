@@ -36,7 +36,9 @@ def main():
             IO.write_ply(f, raw)
             files.append(f); raw_n.append(len(raw))
         pairs.append(dict(src_path=files[0], tgt_path=files[1], relt_pose=p["T_gt"]))
-    run = harness.Runner(cfg, pw, device=0, inflight=3, max_raw_points=max(raw_n), max_points=90000)
+    mode = sys.argv[2] if len(sys.argv) > 2 else "reference"
+    inflight = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    run = harness.Runner(cfg, pw, device=0, inflight=inflight, max_raw_points=max(raw_n), max_points=90000, rng=mode)
     np.random.seed(0)
     run.run(pairs[:4])                         # warm-up
     torch.cuda.synchronize()
@@ -47,7 +49,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(json.dumps(dict(metric="pairs/s incl. file read, H2D, voxel analysis, down-sampling, shuffle, host RNG", value=round(n_pairs / dt, 3),
-                          ms_per_pair=round(dt / n_pairs * 1e3, 2), pairs=n_pairs, mean_raw_points=int(np.mean(raw_n)),
+                          ms_per_pair=round(dt / n_pairs * 1e3, 2), pairs=n_pairs, rng=mode, inflight=inflight, mean_raw_points=int(np.mean(raw_n)),
                           host_prep_ms_per_pair=round(float(np.mean(rows[:, 8])) * 1e3, 2),
                           gpu_latency_ms_per_pair=round(float(np.mean(rows[:, 9])) * 1e3, 2),
                           host_ms_per_pair={k: round(v / n_pairs * 1e3, 2) for k, v in run.timers.items()})))
