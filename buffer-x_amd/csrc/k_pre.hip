@@ -184,19 +184,33 @@ __global__ __launch_bounds__(256) void pre_reduce_kernel(const float* __restrict
     if (pos[i] != s0) return;
     const int k = (c + 1 < nslots ? start[c + 1] : n) - s0;
     int* sg = seg + s0;
-    for (int a = 1; a < k; ++a) {            // insertion sort: voxels hold a handful of points
-        const int v = sg[a];
-        int b = a - 1;
-        while (b >= 0 && sg[b] > v) { sg[b + 1] = sg[b]; --b; }
-        sg[b + 1] = v;
-    }
     double sx = 0.0, sy = 0.0, sz = 0.0;
-    for (int a = 0; a < k; ++a) {
-        const size_t j = (size_t)sg[a] * 3;
-        sx += (double)pts[j]; sy += (double)pts[j + 1]; sz += (double)pts[j + 2];
+    int im;
+    if (k <= 256) {
+        for (int a = 1; a < k; ++a) {        // insertion sort: voxels hold a handful of points (<= 32 k moves at the cut-over)
+            const int v = sg[a];
+            int b = a - 1;
+            while (b >= 0 && sg[b] > v) { sg[b + 1] = sg[b]; --b; }
+            sg[b + 1] = v;
+        }
+        for (int a = 0; a < k; ++a) {
+            const size_t j = (size_t)sg[a] * 3;
+            sx += (double)pts[j]; sy += (double)pts[j + 1]; sz += (double)pts[j + 2];
+        }
+        im = sg[0];
+    } else {
+        // a crowded voxel (voxel size large against the sampling density): sorting its k members would be O(k^2) in one thread;
+        // walking ALL points in index order and picking its members is O(n), bounded, and the same summation order
+        im = -1;
+        int left = k;
+        for (int j = 0; j < n && left > 0; ++j) {
+            if (cellid[j] != c) continue;
+            if (im < 0) im = j;
+            sx += (double)pts[(size_t)j * 3]; sy += (double)pts[(size_t)j * 3 + 1]; sz += (double)pts[(size_t)j * 3 + 2];
+            --left;
+        }
     }
     const double dk = (double)k;
-    const int im = sg[0];
     cen[(size_t)im * 3] = (float)(sx / dk);
     cen[(size_t)im * 3 + 1] = (float)(sy / dk);
     cen[(size_t)im * 3 + 2] = (float)(sz / dk);
