@@ -37,6 +37,22 @@ def test_voxel_downsample_exact(pctx, seed, n, vs):
     assert np.array_equal(out[:m].cpu().numpy(), ref)
 
 
+def test_voxel_downsample_crowded_voxels(pctx):
+    """Voxels with tens of thousands of members (voxel size large against the density): the per-voxel reduction switches from
+    sorting its members to an index-order walk; same binary64 summation order, bounded work."""
+    from oracle import pre_oracle as PO
+    rng = np.random.default_rng(8)
+    pts = np.concatenate([rng.random((60000, 3), np.float32) * np.float32(0.9),                 # one voxel with 60 k points
+                          rng.random((3000, 3), np.float32) * 4 + np.float32([2, 0, 0]),         # sparse part
+                          np.tile(np.float32([[5.5, 5.5, 5.5]]), (700, 1))]).astype(np.float32)  # 700 identical points
+    pts = pts[rng.permutation(len(pts))]
+    for vs in (1.0, 0.25):
+        out, cnt = pctx.pre_voxel_downsample(pts, vs)
+        m, status = (int(v) for v in cnt.cpu().numpy())
+        ref = PO.voxel_down_sample(pts, vs)
+        assert status == 0 and m == len(ref) and np.array_equal(out[:m].cpu().numpy(), ref)
+
+
 def test_voxel_downsample_real_like_cloud(pctx, bx):
     from oracle import pre_oracle as PO
     pair = bx.synth.make_pair(11, "indoor", n_target=30000, voxel=0.008)   # dense "raw" fragment
