@@ -539,7 +539,9 @@ int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, cons
         // Configuration by measurement (tools/gpu_conv.sh, K = 5000): 8 waves; 2 units per workgroup for the 64- and
         // 32-channel layers (9 / 5 accumulator tiles per wave), 1 unit for the 128-channel layers.  Variants tried and
         // found within +-2 %: 4-wave workgroups, two column tiles per wave (NPW = 2), a persistent group walk,
-        // pinned accumulator interleaving (10 % slower).  The stack sits at ~113 TFLOP/s in every variant.
+        // pinned accumulator interleaving (10 % slower).  Re-measured on the final kernel (127.4 TFLOP/s stand-alone) for the two
+        // 128-channel layers: NPW = 2 with 8 waves / G = 2 (127.5) and with 4 waves (127.6) -- halving the A-operand LDS reads
+        // changes nothing, so the LDS read rate is not what holds the stack at 0.81 of the f32 MFMA peak.
         switch (layer) {
             //                     NCHUNK taps P_IN P_LDS P_OUT COUT G  RELU
             case 0: return launch_conv<3, 9, 140, CYL, 140, 64, 2, true>(s, L, in, units_dev, max_units, out, c->skip);
