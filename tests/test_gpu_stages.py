@@ -391,3 +391,17 @@ def test_ball_group_long_candidate_sequences(bx, oracle, packed, n, r, nkp):
         assert np.array_equal(_np(idx), ridx) and np.array_equal(_np(patches), rp)
     finally:
         c.close()
+
+
+def test_fps_kitti_size_cloud(bx, oracle, packed):
+    """BASELINE configs[2]: ~120k-point clouds -> 8 cooperating FPS workgroups per cloud (granule exchange), bit-exact indices."""
+    from bufferx_amd import lib
+    rng = np.random.default_rng(120)
+    xyz = (rng.normal(size=(125000, 3)) * [30, 30, 2]).astype(np.float32)
+    c = lib.Context(_cfg(bx, K=256, P=128, S=2, nk=256), max_points=130000, device=0, packed_weights=packed)
+    try:
+        idx, kp = c.fps(xyz, 96)
+        ref = oracle.fps(xyz, 96)
+        assert np.array_equal(_np(idx), ref) and np.array_equal(_np(kp), xyz[ref])
+    finally:
+        c.close()
