@@ -3,8 +3,8 @@ batched for pairs that were sharded over ranks.
 
     compute_rte / compute_rre            <- utils/SE3.py:134-165
     write_3dmatch_logs                   <- test.py:150-165 (one "a+" open per pair there; here ONE write per scene, same bytes)
-    read_trajectory / read_trajectory_info / computeTransformationErr / evaluate_registration
-                                         <- utils/tools.py:67-129 (nibabel.quaternions.mat2quat restated in mat2quat below)
+    loadlog / read_trajectory / read_trajectory_info / computeTransformationErr / evaluate_registration
+                                         <- utils/tools.py:49-129 (nibabel.quaternions.mat2quat restated in mat2quat below)
     summarize                            <- test.py:255-270, 327-338 (recall, RTE / RRE mean +- std, inlier statistics, timings with
                                             the first FIRST_A_FEW_FRAMES = 5 pairs excluded)
     save_per_sample_results              <- utils/result_io.py:7-50
@@ -65,6 +65,21 @@ def _blocks(filename, rows):
         lines = f.readlines()
     nb = (len(lines) + rows) // (rows + 1)
     return [lines[b * (rows + 1):(b + 1) * (rows + 1)] for b in range(nb)]
+
+
+def loadlog(gtpath):
+    """{"<i>_<j>": float64 [4,4]} from <gtpath>/gt.log (utils/tools.py:49-64; the 3DMatch loader inverts these into relt_pose,
+    dataset/threedmatch.py:123)."""
+    out = {}
+    for blk in _blocks(os.path.join(gtpath, "gt.log"), 4):
+        if len(blk) < 5:
+            break
+        head = blk[0].replace("\n", "").split("\t")[0:3]
+        T = np.zeros([4, 4])
+        for r in range(4):
+            T[r] = [float(x) for x in blk[1 + r].replace("\n", "").split("\t")[0:4]]
+        out[f"{int(head[0])}_{int(head[1])}"] = T
+    return out
 
 
 def read_trajectory(filename, dim=4):

@@ -111,7 +111,8 @@ def main():
         nfr, gt_cov = T.read_trajectory_info(os.path.join(gtroot, scene, "gt.info"))
         est_pairs, est_traj = T.read_trajectory(os.path.join("logs/log_3DMatch", scene, f"{timestr}.log"))
         prec, rec, flags, errs = T.evaluate_registration(nfr, est_traj, est_pairs, gt_pairs, gt_traj, gt_cov)
-        ev[scene] = dict(prec=prec, rec=rec, flags=np.array(flags), errs=errs, nfr=nfr, gt_pairs=gt_pairs, gt_traj=gt_traj, gt_cov=gt_cov,
+        gl = T.loadlog(os.path.join(gtroot, scene))
+        ev[scene] = dict(loadlog_keys=np.array(list(gl.keys())), loadlog_mats=np.array([gl[k] for k in gl]), prec=prec, rec=rec, flags=np.array(flags), errs=errs, nfr=nfr, gt_pairs=gt_pairs, gt_traj=gt_traj, gt_cov=gt_cov,
                          est_pairs=est_pairs, est_traj=est_traj)
     ns = {"np": np, "states": [list(map(float, s)) for s in states]}
     exec(stats_block, ns)

@@ -48,6 +48,9 @@ def test_trajectory_readers_and_rmse_recall(ev, gold):
         assert np.array_equal(gp, gold[f"{scene}|gt_pairs"]) and np.array_equal(gt, gold[f"{scene}|gt_traj"])
         assert nfr == int(gold[f"{scene}|nfr"]) and np.array_equal(cov, gold[f"{scene}|gt_cov"])
         assert np.array_equal(ep, gold[f"{scene}|est_pairs"]) and np.array_equal(et, gold[f"{scene}|est_traj"])
+        gl = ev.loadlog(os.path.join(G, "gt_result", scene))
+        assert list(gl.keys()) == [str(k) for k in gold[f"{scene}|loadlog_keys"]]
+        assert np.array_equal(np.array([gl[k] for k in gl]), gold[f"{scene}|loadlog_mats"])
         prec, rec2, flags, errs = ev.evaluate_registration(nfr, et, ep, gp, gt, cov)
         assert rec == rec2 == float(gold[f"{scene}|rec"]) and prec == float(gold[f"{scene}|prec"])
         assert np.array_equal(np.array(flags), gold[f"{scene}|flags"])
