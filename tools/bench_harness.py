@@ -18,7 +18,12 @@ def main():
     import torch
     import bufferx_amd as bx
     from bufferx_amd import harness
-    from oracle import io_oracle as IO          # only to WRITE the input files
+
+    def write_ply(path, pts):                   # binary little-endian PLY, x y z float32 (what 3DMatch fragments look like)
+        with open(path, "wb") as f:
+            f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\n"
+                     "property float z\nend_header\n" % len(pts)).encode("ascii"))
+            f.write(np.ascontiguousarray(pts, "<f4").tobytes())
     n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     cfg = bx.make_cfg("3DMatch")
     cfg.patch.num_fps, cfg.patch.num_points_per_patch, cfg.patch.num_scales = 5000, 1024, 3
@@ -33,7 +38,7 @@ def main():
         for k, c in (("s", p["src"]), ("t", p["tgt"])):
             raw = np.concatenate([c + rng.normal(0, 0.003, c.shape) for _ in range(4)]).astype(np.float32)
             f = os.path.join(d, f"{k}{i}.ply")
-            IO.write_ply(f, raw)
+            write_ply(f, raw)
             files.append(f); raw_n.append(len(raw))
         pairs.append(dict(src_path=files[0], tgt_path=files[1], relt_pose=p["T_gt"]))
     mode = sys.argv[2] if len(sys.argv) > 2 else "reference"

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """tools/bench_pre.py -- timing of the GPU pre-processing entry points (bx_pre_voxel_downsample, bx_pre_pca) on a raw-sized cloud,
-with the CPU restatement (oracle/pre_oracle.py, numpy) timed beside it.  Prints one JSON line."""
+(GPU time per call, hipEvent-timed).  Prints one JSON line."""
 import json
 import os
 import sys
@@ -16,7 +16,6 @@ def main():
     import torch
     import bufferx_amd as bx
     from bufferx_amd import lib
-    from oracle import pre_oracle as PO
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300000
     vs = float(sys.argv[2]) if len(sys.argv) > 2 else 0.025
     rng = np.random.default_rng(0)
@@ -42,10 +41,8 @@ def main():
         return a.elapsed_time(b) / it
     ms_vox = t(lambda: ctx.pre_voxel_downsample(d, vs))
     ms_pca = t(lambda: ctx.pre_pca(d, idx))
-    t0 = time.perf_counter(); ref = PO.voxel_down_sample(pts, vs); cpu_vox = (time.perf_counter() - t0) * 1e3
-    t0 = time.perf_counter(); PO.pca_stats(pts, idx.cpu().numpy()); cpu_pca = (time.perf_counter() - t0) * 1e3
-    print(json.dumps(dict(n=n, voxel=vs, voxels=len(ref), gpu_voxel_ms=round(ms_vox, 3), gpu_pca_ms=round(ms_pca, 3),
-                          cpu_numpy_voxel_ms=round(cpu_vox, 1), cpu_numpy_pca_ms=round(cpu_pca, 1))))
+    m = int(ctx.pre_voxel_downsample(d, vs)[1].cpu().numpy()[0])
+    print(json.dumps(dict(n=n, voxel=vs, voxels=m, gpu_voxel_ms=round(ms_vox, 3), gpu_pca_ms=round(ms_pca, 3))))
     ctx.close()
 
 
