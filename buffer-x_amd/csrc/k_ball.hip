@@ -361,8 +361,8 @@ __device__ __forceinline__ void set_hit(unsigned int* bm32, int i)
 //   2. hits set their bit in an LDS bitmap (bit = permuted point index): this restores the index order the reference's
 //      ball_query scans in, whatever order the grid delivered the candidates in.
 //   3. rank of a hit = set bits below it = prefix[word] + popcount(word & below): when all candidates of the keypoint were held in
-//      registers (one block of QU chunks per wave: the common case) every hit computes its own rank and drops its index into
-//      list[rank] -- no per-bit loops; otherwise the owners of the bitmap words expand their bits in order.
+//      registers (up to two blocks of QU chunks per wave: the common case) every hit computes its own rank and drops its index
+//      into list[rank] -- no per-bit loops; otherwise the owners of the bitmap words expand their bits in order.
 //   4. output: gather + mask arithmetic from the ordered list, 768 contiguous bytes per wave store.
 // LDS: bitmap (n/8 B) | per-word prefix (n/16 B) | list (4 P B).
 template <int LOGC, int QW>
@@ -413,14 +413,17 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
     __syncthreads();                                        // bitmap zeroed
     if (tr) td[7] = T;
 
-    const bool one_block = R >= 0 && T <= QT * QU;          // uniform: every candidate is held in a register of some lane
-    int hidx[QU];                                           // one_block: index of the hit in slot u, -1 otherwise
+    constexpr int NBLK = 2;                                 // register blocks (QU chunks per wave each) whose hits can rank themselves
+    const bool one_block = R >= 0 && T <= QT * QU * NBLK;   // uniform: every candidate is tested from a register that is kept
+    int hidx[QU * NBLK];                                    // one_block: index of the hit in slot (block, u), -1 otherwise
+#pragma unroll
+    for (int u = 0; u < QU * NBLK; ++u) hidx[u] = -1;
     if (R >= 0) {
         int rb = 0;                                         // wave-uniform (SGPR): first row whose end lies beyond the chunk start
-        for (int c0 = 0; c0 * 64 < T; c0 += QW * QU) {
-            // the loads of a block go out back to back and are waited for once (a load under a DIVERGENT branch is waited for
-            // right behind its issue: the merge with the not-taken value needs the data); chunks beyond T are skipped by
-            // scalar branches, lanes beyond T read slot 0 (a valid point) and are masked in the test
+        // one block: QU chunks per wave.  The loads go out back to back and are waited for once (a load under a DIVERGENT branch
+        // is waited for right behind its issue: the merge with the not-taken value needs the data); chunks beyond T are skipped
+        // by scalar branches, lanes beyond T read slot 0 (a valid point) and are masked in the test
+        auto scan_block = [&](int c0, int* hx) {
             float4 c[QU];
 #pragma unroll
             for (int u = 0; u < QU; ++u) {
@@ -453,17 +456,24 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
 #pragma unroll
             for (int u = 0; u < QU; ++u) {
                 const int vc = (c0 + u * QW + wave) * 64;
-                hidx[u] = -1;
                 if (vc < T) {                               // uniform
                     const float ax = qx - c[u].x, ay = qy - c[u].y, az = qz - c[u].z;
                     const float d2 = (ax * ax + ay * ay) + az * az;
                     if (d2 < r2 && vc + lane < T) {
                         const int i = __float_as_int(c[u].w);
                         set_hit(bm32, i);
-                        hidx[u] = i;
+                        hx[u] = i;
                     }
                 }
             }
+        };
+        if (one_block) {
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b)
+                if (b * QW * QU * 64 < T) scan_block(b * QW * QU, hidx + b * QU);      // uniform
+        } else {
+            int dump[QU];
+            for (int c0 = 0; c0 * 64 < T; c0 += QW * QU) scan_block(c0, dump);
         }
     } else {
         // degenerate geometry (cell edge << radius because of the 1024-cells-per-axis floor): plain nested walk
@@ -521,7 +531,7 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < QU; ++u) {
+        for (int u = 0; u < QU * NBLK; ++u) {
             const int i = hidx[u];
             if (i >= 0) {
                 const int w = i >> 6;
