@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <exception>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -137,7 +138,11 @@ int read_ply(const FileBuf& fb, const char* path, float* out, int64_t cap, int64
         const std::vector<std::string> w = split_ws(line);
         if (w.empty()) continue;
         if (w[0] == "format" && w.size() >= 2) fmt = w[1] == "ascii" ? 0 : (w[1] == "binary_little_endian" ? 1 : (w[1] == "binary_big_endian" ? 2 : -1));
-        else if (w[0] == "element" && w.size() >= 3) { PlyElem e; e.name = w[1]; e.count = atoll(w[2].c_str()); elems.push_back(e); }
+        else if (w[0] == "element" && w.size() >= 3) {
+            PlyElem e; e.name = w[1]; e.count = atoll(w[2].c_str());
+            if (e.count < 0 || e.count > ((int64_t)1 << 40)) { bx_set_error("bx_io: %s: element count %s out of range", path, w[2].c_str()); return BX_ERR_ARG; }
+            elems.push_back(e);
+        }
         else if (w[0] == "property" && !elems.empty()) {
             PlyProp p;
             if (w.size() >= 5 && w[1] == "list") { p.is_list = true; p.count_t = ply_type(w[2]); p.t = ply_type(w[3]); p.name = w[4]; }
@@ -283,6 +288,12 @@ int read_pcd(const FileBuf& fb, const char* path, float* out, int64_t cap, int64
     }
     if (counts.size() != fields.size()) counts.assign(fields.size(), 1);
     const int64_t n = points >= 0 ? points : width * height;
+    if (n < 0 || n > ((int64_t)1 << 40) || width < 0 || height < 0) { bx_set_error("bx_io: %s: point count out of range", path); return BX_ERR_ARG; }
+    for (size_t k = 0; k < fields.size(); ++k)
+        if (sizes[k] < 1 || sizes[k] > 8 || (counts.size() == fields.size() && (counts[k] < 1 || counts[k] > 4096))) {
+            bx_set_error("bx_io: %s: field size / count out of range", path);
+            return BX_ERR_ARG;
+        }
     *n_out = n;
     if (!out) return BX_OK;
     if (n > cap) { bx_set_error("bx_io: %s holds %lld points, buffer holds %lld", path, (long long)n, (long long)cap); return BX_ERR_ARG; }
@@ -342,7 +353,7 @@ int read_pcd(const FileBuf& fb, const char* path, float* out, int64_t cap, int64
         uint32_t csz, usz;
         memcpy(&csz, fb.d.data() + pos, 4); memcpy(&usz, fb.d.data() + pos + 4, 4);
         pos += 8;
-        if (pos + csz > fb.d.size() || (size_t)usz < stride * (size_t)n) { bx_set_error("bx_io: %s: inconsistent compressed PCD sizes", path); return BX_ERR_ARG; }
+        if (pos + csz > fb.d.size() || (size_t)usz != stride * (size_t)n) { bx_set_error("bx_io: %s: inconsistent compressed PCD sizes", path); return BX_ERR_ARG; }
         std::vector<unsigned char> raw(usz);
         if (!lzf_decompress(fb.d.data() + pos, csz, raw.data(), usz)) { bx_set_error("bx_io: %s: LZF stream is corrupt", path); return BX_ERR_ARG; }
         // field-major layout: all values of field 0, then field 1, ...
@@ -375,7 +386,22 @@ int read_bin(const FileBuf& fb, const char* path, float* out, int64_t cap, int64
     return BX_OK;
 }
 
+int read_any_impl(const char* path, float* out, int64_t cap, int64_t* n_out);
+
+// nothing may unwind through the C boundary or out of the worker thread (a corrupt header can ask for an absurd allocation)
 int read_any(const char* path, float* out, int64_t cap, int64_t* n_out)
+{
+    try {
+        return read_any_impl(path, out, cap, n_out);
+    } catch (const std::exception& e) {
+        bx_set_error("bx_io: %s: %s", path ? path : "(null)", e.what());
+    } catch (...) {
+        bx_set_error("bx_io: %s: unexpected exception", path ? path : "(null)");
+    }
+    return BX_ERR_ARG;
+}
+
+int read_any_impl(const char* path, float* out, int64_t cap, int64_t* n_out)
 {
     if (!path || !n_out) { bx_set_error("bx_io: null argument"); return BX_ERR_ARG; }
     FileBuf fb;

@@ -82,7 +82,8 @@ class BxError(RuntimeError):
 
 def _chk(rc, what):
     if rc != 0:
-        raise BxError(f"{what} failed (status {rc}): {load().bx_last_error().decode()}")
+        msg = load().bx_last_error().decode(errors="replace")       # a message may quote bytes of a corrupt input file
+        raise BxError(f"{what} failed (status {rc}): {msg}")
 
 
 def params_from_cfg(cfg, max_points):

@@ -103,3 +103,50 @@ def test_lzf_reference_vector():
     assert IO.lzf_decompress(stream, 12) == b"abcabcabcabc"
     data = bytes(np.random.default_rng(0).integers(0, 3, 4000, dtype=np.uint8)) + b"\0" * 1000
     assert IO.lzf_decompress(IO.lzf_compress(data), len(data)) == data
+
+
+def test_corrupt_files_never_crash(tmp_path, ing):
+    """Byte flips, truncations, inserted bytes and altered header digits: the readers either return an [n,3] float32 array or raise
+    BxError -- no exception crosses the C boundary, no out-of-bounds access (400 mutated files over all seven storage modes)."""
+    from bufferx_amd import lib
+    rng = np.random.default_rng(99)
+    pts = rng.normal(size=(200, 3)).astype(np.float32)
+    seeds = []
+    for fmt in ("ascii", "binary_little_endian", "binary_big_endian"):
+        f = str(tmp_path / f"a_{fmt}.ply")
+        IO.write_ply(f, pts, fmt, extra=[("nx", "float", pts[:, 0])], faces=rng.integers(0, 200, (4, 3)), face_first=(fmt != "ascii"))
+        seeds.append(f)
+    for mode in ("ascii", "binary", "binary_compressed"):
+        f = str(tmp_path / f"b_{mode}.pcd")
+        IO.write_pcd(f, pts, mode, extra=[("i", "F4", pts[:, 0])])
+        seeds.append(f)
+    f = str(tmp_path / "c.bin")
+    np.concatenate([pts, pts[:, :1]], 1).tofile(f)
+    seeds.append(f)
+    ok = err = 0
+    for it in range(400):
+        src = seeds[it % len(seeds)]
+        raw = bytearray(open(src, "rb").read())
+        mode = int(rng.integers(0, 4))
+        if mode == 0:
+            for _ in range(int(rng.integers(1, 6))):
+                raw[int(rng.integers(0, len(raw)))] = int(rng.integers(0, 256))
+        elif mode == 1:
+            raw = raw[:int(rng.integers(0, len(raw)))]
+        elif mode == 2:
+            for _ in range(4):
+                i = int(rng.integers(0, min(len(raw), 300)))
+                if 48 <= raw[i] <= 57:
+                    raw[i] = int(rng.integers(48, 58))
+        else:
+            i = int(rng.integers(0, len(raw)))
+            raw[i:i] = bytes(rng.integers(0, 256, int(rng.integers(1, 20)), dtype=np.uint8))
+        out = str(tmp_path / ("f" + os.path.splitext(src)[1]))
+        open(out, "wb").write(bytes(raw))
+        try:
+            a = ing.read_point_cloud(out)
+            assert a.ndim == 2 and a.shape[1] == 3 and a.dtype == np.float32
+            ok += 1
+        except (lib.BxError, MemoryError, ValueError):
+            err += 1
+    assert ok + err == 400 and err > 50
