@@ -207,3 +207,43 @@ class Runner:
         for c in range(C):
             harvest(c)
         return np.stack(rows) if n else np.zeros((0, evaluate.STATE_W)), poses
+
+
+# ---------------------------------------------------------------------------------------------------- 3DMatch test split
+THREEDMATCH_TEST_SCENES = ("7-scenes-redkitchen", "sun3d-home_at-home_at_scan1_2013_jan_1", "sun3d-home_md-home_md_scan9_2012_sep_30",
+                           "sun3d-hotel_uc-scan3", "sun3d-hotel_umd-maryland_hotel1", "sun3d-hotel_umd-maryland_hotel3",
+                           "sun3d-mit_76_studyroom-76-1studyroom2", "sun3d-mit_lab_hj-lab_hj_tea_nov_2_2012_scan1_erika")
+
+
+def threedmatch_test_pairs(root, benchmark="3DMatch", scenes=THREEDMATCH_TEST_SCENES):
+    """The pair list of ThreeDMatchDataset(split="test") (dataset/threedmatch.py:36-63) in the form Runner.run takes: one dict per
+    gt.log entry, in file order, with src_id / tgt_id as the loader names them ("3DMatch/fragments/<scene>/cloud_bin_<k>"), the
+    .ply paths under <root>/test (dataset/threedmatch.py:73-79) and relt_pose = inv(gt) (dataset/threedmatch.py:123)."""
+    test_root = os.path.join(root, "test")
+    pairs = []
+    for scene in scenes:
+        gtpath = test_root + (f"/{benchmark}/gt_result/{scene}" if benchmark == "3DMatch" else f"/{benchmark}/{scene}")
+        for key, gt in evaluate.loadlog(gtpath).items():
+            id1, id2 = key.split("_")[0], key.split("_")[1]
+            src_id = os.path.join(f"3DMatch/fragments/{scene}", f"cloud_bin_{id1}")
+            tgt_id = os.path.join(f"3DMatch/fragments/{scene}", f"cloud_bin_{id2}")
+            pairs.append(dict(src_id=src_id, tgt_id=tgt_id, src_path=os.path.join(test_root, src_id) + ".ply",
+                              tgt_path=os.path.join(test_root, tgt_id) + ".ply", relt_pose=np.linalg.inv(gt)))
+    return pairs
+
+
+def run_3dmatch(cfg, packed_weights, root, benchmark="3DMatch", timestr="run", out_root=".", **runner_kw):
+    """test.py for the 3DMatch / 3DLoMatch test split on one GPU: pair list -> Runner -> .log files -> RMSE recall + summary."""
+    pairs = threedmatch_test_pairs(root, benchmark)
+    run = Runner(cfg, packed_weights, **runner_kw)
+    try:
+        rows, poses = run.run(pairs)
+    finally:
+        run.close()
+    evaluate.write_3dmatch_logs(benchmark, timestr, [(p["src_id"], p["tgt_id"], pose) for p, pose in zip(pairs, poses)], root=out_root)
+    gtpath = os.path.join(root, "test", benchmark, "gt_result") if benchmark == "3DMatch" else os.path.join(root, "test", benchmark)
+    scenes, rmse_recall = evaluate.evaluate_3dmatch(gtpath, benchmark, timestr, root=out_root)
+    summary = evaluate.summarize(evaluate.states_matrix(rows))
+    summary["rmse_recall"] = float(np.mean(rmse_recall))
+    summary["scene_recall"] = dict(zip(scenes, rmse_recall))
+    return rows, summary

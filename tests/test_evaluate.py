@@ -137,3 +137,19 @@ def test_sharded_states_one_allgather_world2(tmp_path):
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "rank0ok" in out.stdout and "rank1ok" in out.stdout
+
+
+def test_threedmatch_test_pair_list(tmp_path):
+    """harness.threedmatch_test_pairs against the file list and poses of the real ThreeDMatchDataset(split="test")
+    (tests/golden/make_golden_pairs.py)."""
+    from bufferx_amd import harness
+    g = np.load(os.path.join(G, "pairs.npz"))
+    root = tmp_path / "data"
+    (root / "test" / "3DMatch").mkdir(parents=True)
+    os.symlink(os.path.join(G, "gt_result"), root / "test" / "3DMatch" / "gt_result")
+    scenes = [s for s in harness.THREEDMATCH_TEST_SCENES if os.path.isdir(os.path.join(G, "gt_result", s))]
+    pairs = harness.threedmatch_test_pairs(str(root), "3DMatch", scenes)
+    assert [[p["src_id"], p["tgt_id"]] for p in pairs] == [list(map(str, f)) for f in g["files"]]
+    for p, gt in zip(pairs, g["poses"]):
+        assert np.array_equal(p["relt_pose"], np.linalg.inv(gt))            # dataset/threedmatch.py:123
+        assert p["src_path"] == os.path.join(str(root), "test", p["src_id"]) + ".ply"
