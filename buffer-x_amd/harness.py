@@ -232,9 +232,9 @@ def threedmatch_test_pairs(root, benchmark="3DMatch", scenes=THREEDMATCH_TEST_SC
     return pairs
 
 
-def run_3dmatch(cfg, packed_weights, root, benchmark="3DMatch", timestr="run", out_root=".", **runner_kw):
+def run_3dmatch(cfg, packed_weights, root, benchmark="3DMatch", timestr="run", out_root=".", scenes=THREEDMATCH_TEST_SCENES, **runner_kw):
     """test.py for the 3DMatch / 3DLoMatch test split on one GPU: pair list -> Runner -> .log files -> RMSE recall + summary."""
-    pairs = threedmatch_test_pairs(root, benchmark)
+    pairs = threedmatch_test_pairs(root, benchmark, scenes)
     run = Runner(cfg, packed_weights, **runner_kw)
     try:
         rows, poses = run.run(pairs)

@@ -1,5 +1,7 @@
 """End-to-end pipeline on the GPU (buffer-x_amd/harness.py): files -> prefetch -> GPU pre-processing -> pairs in flight -> metrics,
 against the same steps made one by one, synchronously, with the same NumPy seed (bit-identical poses), and the evaluation rows."""
+import os
+
 import numpy as np
 import pytest
 
@@ -94,3 +96,31 @@ def test_runner_device_rng_is_deterministic(tmp_path, bx, packed):
     assert np.array_equal(out[0][0][:, :8], out[1][0][:, :8]) and np.array_equal(out[0][0][:, 13:], out[1][0][:, 13:])
     assert all(np.array_equal(a, b) for a, b in zip(out[0][1], out[1][1]))
     assert (out[0][0][:, 5] > 0).all()        # mutual matches were found: the permutations fed real neighbourhoods
+
+
+def test_run_3dmatch_end_to_end(tmp_path, bx, packed):
+    """A miniature 3DMatch test split on disk (fragments as .ply, gt.log, gt.info) through harness.run_3dmatch: pair list -> pipeline ->
+    .log files -> RMSE recall; noise-free pairs with the real thresholds must register."""
+    from bufferx_amd import evaluate, harness
+    scene = harness.THREEDMATCH_TEST_SCENES[0]
+    root = tmp_path / "data"
+    frag = root / "test" / "3DMatch" / "fragments" / scene
+    gtd = root / "test" / "3DMatch" / "gt_result" / scene
+    frag.mkdir(parents=True); gtd.mkdir(parents=True)
+    log, info = [], []
+    for k, (i, j) in enumerate([(0, 2), (3, 5)]):
+        p = bx.synth.make_pair(60 + k, "indoor", n_target=9000, jitter=0.0, identical=True)
+        IO.write_ply(str(frag / f"cloud_bin_{i}.ply"), p["src"])
+        IO.write_ply(str(frag / f"cloud_bin_{j}.ply"), p["tgt"])
+        G = np.linalg.inv(p["T_gt"])                      # the loader uses relt_pose = inv(gt.log entry)
+        log.append(f"{i}\t {j}\t 6\n" + "".join("\t".join(repr(float(v)) for v in G[r]) + "\t\n" for r in range(4)))
+        info.append(f"{i}\t {j}\t 6\n" + "".join("\t".join(repr(float(v)) for v in np.eye(6)[r] * 100) + "\t\n" for r in range(6)))
+    (gtd / "gt.log").write_text("".join(log)); (gtd / "gt.info").write_text("".join(info))
+    cfg = _cfg(bx)
+    np.random.seed(2)
+    rows, summary = harness.run_3dmatch(cfg, packed, str(root), "3DMatch", "T0", out_root=str(tmp_path), scenes=[scene],
+                                        inflight=2, max_raw_points=40000, max_points=40000, rng="device")
+    assert rows.shape[0] == 2 and os.path.exists(tmp_path / "logs" / "log_3DMatch" / scene / "T0.log")
+    assert set(summary["scene_recall"]) == {scene} and 0.0 <= summary["rmse_recall"] <= 1.0
+    est_pairs, est_traj = evaluate.read_trajectory(str(tmp_path / "logs" / "log_3DMatch" / scene / "T0.log"))
+    assert est_pairs[:, :2].tolist() == [["0", "2"], ["3", "5"]] and est_traj.shape == (2, 4, 4)
