@@ -138,8 +138,15 @@ __global__ void ransac_scan_kernel(const int32_t* __restrict__ C_dev, int max_C,
                                    const double* __restrict__ r_err, const double* __restrict__ r_T, int last,
                                    double* __restrict__ T_out, int32_t* __restrict__ info_out)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // the batch's inlier counts and squared-error sums are staged in LDS by the whole workgroup (coalesced), then ONE thread
+    // replays Open3D's sequential best-so-far / iteration-bound update over them: a single thread reading 4096 slots straight from
+    // global memory cost ~0.3 ms per batch, i.e. 4 ms per pair at confidence 1.0 (all 50 000 iterations)
+    __shared__ int s_inl[BX_RANSAC_BATCH];
+    __shared__ double s_err[BX_RANSAC_BATCH];
     if (skip_flag && *skip_flag) return;
+    for (int i = threadIdx.x; i < BX_RANSAC_BATCH; i += blockDim.x) { s_inl[i] = r_inl[i]; s_err[i] = r_err[i]; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     int C = *C_dev;
     C = C < max_C ? C : max_C;
     int est_k = st->r_est_k < cfg.max_iter ? st->r_est_k : cfg.max_iter;
@@ -150,9 +157,9 @@ __global__ void ransac_scan_kernel(const int32_t* __restrict__ C_dev, int max_C,
         for (int slot = 0; slot < BX_RANSAC_BATCH; ++slot) {
             itr = it0 + slot;
             if (itr >= cfg.max_iter || itr >= est_k) break;
-            int inl = r_inl[slot];
+            int inl = s_inl[slot];
             if (inl >= 0) {
-                double rmse = inl > 0 ? sqrt(r_err[slot] / (double)inl) : 0.0;
+                double rmse = inl > 0 ? sqrt(s_err[slot] / (double)inl) : 0.0;
                 if (inl > best_inl || (inl == best_inl && rmse < best_rmse)) {
                     best_inl = inl; best_rmse = rmse;
                     for (int i = 0; i < 12; ++i) st->T[i] = r_T[(size_t)slot * 12 + i];
@@ -292,7 +299,7 @@ int bxk_ransac(bx_ctx* c, hipStream_t s, const float* ss, const float* tt, const
         if (max_C >= 3 && cfg.max_iter > 0)
             hipLaunchKernelGGL(ransac_eval_kernel, dim3(BX_RANSAC_BATCH / 4), dim3(256), 0, s, ss, tt, corr, C_dev, max_C, cfg, it0,
                                c->state, skip_flag, c->ransac_inl, c->ransac_err, c->ransac_T);
-        hipLaunchKernelGGL(ransac_scan_kernel, dim3(1), dim3(1), 0, s, C_dev, max_C, cfg, it0, c->state, skip_flag, c->ransac_inl,
+        hipLaunchKernelGGL(ransac_scan_kernel, dim3(1), dim3(256), 0, s, C_dev, max_C, cfg, it0, c->state, skip_flag, c->ransac_inl,
                            c->ransac_err, c->ransac_T, b == nb - 1 ? 1 : 0, T_out, info_out);
     }
     BX_LAUNCH_CHECK();
