@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <cmath>
 #include <vector>
 
@@ -259,6 +260,22 @@ __global__ void finalize_kernel(const PairState* st, const int32_t* err, int ref
     }
 }
 
+// bx_set_capture: stream-ordered device-to-device copy into a caller buffer (no-op for a null destination)
+template <typename T>
+int cap_copy(hipStream_t s, T* dst, const T* src, size_t n)
+{
+    if (dst && n) BX_HIP(hipMemcpyAsync(dst, src, sizeof(T) * n, hipMemcpyDeviceToDevice, s));
+    return BX_OK;
+}
+
+__global__ void cap_counts_kernel(const PairState* st, int32_t* counts, double* T)
+{
+    if (threadIdx.x == 0 && counts) { counts[0] = st->m_scale; counts[1] = st->M; counts[2] = st->C; counts[3] = st->best; }
+    if (T && threadIdx.x < 16) T[threadIdx.x] = st->T[threadIdx.x];
+}
+
+#define BX_ENTER(c, need_w) int rc; if ((rc = check_ctx((c), (need_w))) != BX_OK) return rc; BxDevScope ds_((c)->device)
+
 int check_ctx(bx_ctx* c, bool need_weights)
 {
     if (!c) { bx_set_error("null context"); return BX_ERR_ARG; }
@@ -302,31 +319,26 @@ extern "C" {
 
 const char* bx_last_error(void) { return g_err; }
 
-int bx_create(int device_id, const bx_params* params, bx_ctx** out)
+static int create_impl(bx_ctx* c, int device_id)
 {
-    if (!params || !out) { bx_set_error("bx_create: null argument"); return BX_ERR_ARG; }
-    const bx_params& p = *params;
-    if (p.rad_n != BX_RAD || p.ele_n != BX_ELE || p.azi_n != BX_AZI) {
-        bx_set_error("bx_create: only rad_n=3, ele_n=7, azi_n=20 are supported (got %d %d %d)", p.rad_n, p.ele_n, p.azi_n);
-        return BX_ERR_ARG;
+    const bx_params& p = c->p;
+    {
+        hipDeviceProp_t prop;
+        BX_HIP(hipGetDeviceProperties(&prop, device_id));
+        c->n_cu = prop.multiProcessorCount;
+        const char* e = getenv("BX_CONV_PERSIST");
+        c->conv_persist = (!e || atoi(e) != 0) ? 1 : 0;
+        e = getenv("BX_CONV_PERSIST_CAP");
+        c->conv_cap_override = e ? atoi(e) : 0;
     }
-    if (p.num_fps < 1 || p.num_points_per_patch < 2 || p.num_scales < 1 || p.num_scales > BX_MAX_SCALES || p.max_points < 1 ||
-        p.num_points_radius_estimate < 1 || p.voxel_sample < 1 || p.voxel_sample > 16) {
-        bx_set_error("bx_create: invalid parameters");
-        return BX_ERR_ARG;
-    }
-    BX_HIP(hipSetDevice(device_id));
-    bx_ctx* c = new bx_ctx();
-    memset(c, 0, sizeof(*c));
-    c->device = device_id;
-    c->p = p;
+    (void)p;
     c->prof = new std::vector<ProfEvt>();
     size_t total = 0;
     carve(c, nullptr, &total);
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->arena), total);
     if (e != hipSuccess) {
+        c->arena = nullptr;
         bx_set_error("bx_create: workspace hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
-        delete c;
         return BX_ERR_HIP;
     }
     c->arena_bytes = (int64_t)total;
@@ -345,7 +357,41 @@ int bx_create(int device_id, const bx_params* params, bx_ctx** out)
         double r = 5.0 * (double)m / 8192.0;
         thr[m] = (float)(r * r);
     }
-    if ((rc = upload(&c->d_rad_thr, thr.data(), thr.size())) != BX_OK) return rc;
+    return upload(&c->d_rad_thr, thr.data(), thr.size());
+}
+
+int bx_create(int device_id, const bx_params* params, bx_ctx** out)
+{
+    if (!params || !out) { bx_set_error("bx_create: null argument"); return BX_ERR_ARG; }
+    const bx_params& p = *params;
+    if (p.rad_n != BX_RAD || p.ele_n != BX_ELE || p.azi_n != BX_AZI) {
+        bx_set_error("bx_create: only rad_n=3, ele_n=7, azi_n=20 are supported (got %d %d %d)", p.rad_n, p.ele_n, p.azi_n);
+        return BX_ERR_ARG;
+    }
+    if (p.num_fps < 1 || p.num_points_per_patch < 2 || p.num_scales < 1 || p.num_scales > BX_MAX_SCALES || p.max_points < 1 ||
+        p.num_points_radius_estimate < 1 || p.voxel_sample < 1 || p.voxel_sample > 16) {
+        bx_set_error("bx_create: invalid parameters");
+        return BX_ERR_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) {
+        bx_set_error("bx_create: device %d not available (%d devices)", device_id, ndev);
+        return BX_ERR_HIP;
+    }
+    BxDevScope ds(device_id);
+    bx_ctx* c = new bx_ctx();
+    memset(c, 0, sizeof(*c));
+    c->device = device_id;
+    c->p = p;
+    const int rc = create_impl(c, device_id);
+    if (rc != BX_OK) {
+        // bx_destroy releases whatever had been allocated; it must not clobber the message of the failure
+        char msg[1024];
+        snprintf(msg, sizeof(msg), "%s", g_err);
+        bx_destroy(c);
+        bx_set_error("%s", msg);
+        return rc;
+    }
     *out = c;
     return BX_OK;
 }
@@ -353,9 +399,14 @@ int bx_create(int device_id, const bx_params* params, bx_ctx** out)
 int bx_destroy(bx_ctx* c)
 {
     if (!c) return BX_OK;
-    (void)hipSetDevice(c->device);
+    BxDevScope ds(c->device);
     (void)hipDeviceSynchronize();
     bxk_pre_release(c);
+    if (c->prof) {
+        auto* v = static_cast<std::vector<ProfEvt>*>(c->prof);
+        for (auto& e : *v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        delete v;
+    }
     (void)hipFree(c->arena);
     (void)hipFree(c->d_centres); (void)hipFree(c->d_rot); (void)hipFree(c->d_rowc); (void)hipFree(c->d_rad_thr);
     (void)hipFree(c->d_pnt_w); (void)hipFree(c->d_pnt_b); (void)hipFree(c->d_pool_w1); (void)hipFree(c->d_pool_b1); (void)hipFree(c->d_pool_w2); (void)hipFree(c->d_pool_b2);
@@ -371,6 +422,19 @@ int bx_debug_read(bx_ctx* c, int64_t* out, int32_t n)
 {
     if (!c || !out || n < 0 || n > 64 * 8) { bx_set_error("bx_debug_read: bad argument"); return BX_ERR_ARG; }
     BX_HIP(hipMemcpy(out, c->ball_dbg, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost));
+    return BX_OK;
+}
+
+int bx_set_capture(bx_ctx* c, const bx_capture* cap)
+{
+    if (!c) { bx_set_error("null context"); return BX_ERR_ARG; }
+    if (!cap) { c->cap_on = 0; return BX_OK; }
+    if (cap->scale < 0 || cap->scale >= c->p.num_scales || cap->cloud < 0 || cap->cloud > 1) {
+        bx_set_error("bx_set_capture: scale %d / cloud %d out of range", cap->scale, cap->cloud);
+        return BX_ERR_ARG;
+    }
+    c->cap = *cap;
+    c->cap_on = 1;
     return BX_OK;
 }
 
@@ -398,10 +462,8 @@ int bx_profile_read(bx_ctx* c, double* ms_out, int32_t* count_out)
 
 int bx_load_weights(bx_ctx* c, const bx_weights* w)
 {
-    int rc;
-    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    BX_ENTER(c, false);
     if (!w) { bx_set_error("bx_load_weights: null"); return BX_ERR_ARG; }
-    BX_HIP(hipSetDevice(c->device));
     if (c->weights_loaded) { bx_set_error("bx_load_weights: already loaded"); return BX_ERR_STATE; }
     if ((rc = upload(&c->d_pnt_w, w->pnt_w, 48)) != BX_OK) return rc;
     if ((rc = upload(&c->d_pnt_b, w->pnt_b, 16)) != BX_OK) return rc;
@@ -466,8 +528,7 @@ int bx_load_weights(bx_ctx* c, const bx_weights* w)
 // ------------------------------------------------------------------------------------------------ stages
 int bx_fps(bx_ctx* c, void* stream, const float* xyz, int32_t n, int32_t m, int32_t* idx_out, float* kpts_out)
 {
-    int rc;
-    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    BX_ENTER(c, false);
     if (!xyz || !idx_out || n < 1 || m < 1) { bx_set_error("bx_fps: bad argument"); return BX_ERR_ARG; }
     const float* xs[1] = {xyz};
     int ns[1] = {n};
@@ -479,8 +540,7 @@ int bx_fps(bx_ctx* c, void* stream, const float* xyz, int32_t n, int32_t m, int3
 int bx_radius(bx_ctx* c, void* stream, const float* pts, int32_t n_pts, int64_t n_orig, const float* kpts, int32_t nk,
               const double* thresholds_host, int32_t nthr, double* des_r_out)
 {
-    int rc;
-    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    BX_ENTER(c, false);
     if (!pts || !kpts || !thresholds_host || !des_r_out || n_pts < 1 || nk < 1) { bx_set_error("bx_radius: bad argument"); return BX_ERR_ARG; }
     if ((rc = bxk_radius_hist(c, (hipStream_t)stream, pts, n_pts, kpts, nk)) != BX_OK) return rc;
     for (int i = 0; i < nthr; ++i)
@@ -490,16 +550,14 @@ int bx_radius(bx_ctx* c, void* stream, const float* pts, int32_t n_pts, int64_t 
 
 int bx_permute(bx_ctx* c, void* stream, const float* pts, const int32_t* perm, int32_t n, float* out)
 {
-    int rc;
-    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    BX_ENTER(c, false);
     return bx_permute_launch((hipStream_t)stream, pts, perm, n, out, nullptr);
 }
 
 int bx_ball_group(bx_ctx* c, void* stream, const float* pts_perm, int32_t n, const float* kpts, int32_t K, const double* radius,
                   int32_t P, int32_t* idx_out, float* patches_out)
 {
-    int rc;
-    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    BX_ENTER(c, false);
     if (!pts_perm || !kpts || !radius || !patches_out) { bx_set_error("bx_ball_group: null argument"); return BX_ERR_ARG; }
     c->skip = nullptr;
     c->ball_waves_hint = 0;
@@ -509,8 +567,7 @@ int bx_ball_group(bx_ctx* c, void* stream, const float* pts_perm, int32_t n, con
 int bx_patch_features(bx_ctx* c, void* stream, const float* patches, int32_t K, int32_t P, const double* radius, int32_t aligned_z,
                       float* R_out, float* feat_out)
 {
-    int rc;
-    if ((rc = check_ctx(c, true)) != BX_OK) return rc;
+    BX_ENTER(c, true);
     if (!patches || !radius || !R_out || !feat_out) { bx_set_error("bx_patch_features: null argument"); return BX_ERR_ARG; }
     c->skip = nullptr;
     return bxk_patch_features(c, (hipStream_t)stream, patches, K, P, radius, aligned_z, R_out, feat_out);
@@ -518,8 +575,7 @@ int bx_patch_features(bx_ctx* c, void* stream, const float* patches, int32_t K, 
 
 int bx_desc_net(bx_ctx* c, void* stream, const float* feat, int32_t K, float* desc_out, float* equi_out, float* x_out)
 {
-    int rc;
-    if ((rc = check_ctx(c, true)) != BX_OK) return rc;
+    BX_ENTER(c, true);
     if (K > c->p.num_fps) { bx_set_error("bx_desc_net: K=%d exceeds context num_fps=%d", K, c->p.num_fps); return BX_ERR_ARG; }
     c->skip = nullptr;
     return desc_stack(c, (hipStream_t)stream, feat, K, desc_out, equi_out, x_out);
@@ -527,8 +583,7 @@ int bx_desc_net(bx_ctx* c, void* stream, const float* feat, int32_t K, float* de
 
 int bx_conv_layer(bx_ctx* c, void* stream, int32_t net, int32_t layer, const float* in, int32_t units, float* out)
 {
-    int rc;
-    if ((rc = check_ctx(c, true)) != BX_OK) return rc;
+    BX_ENTER(c, true);
     if (net == 1 && layer == 0) { bx_set_error("bx_conv_layer: Pose layer 0 consumes the implicit cost volume; use bx_pose_net"); return BX_ERR_ARG; }
     c->skip = nullptr;
     return bxk_conv(c, (hipStream_t)stream, net, layer, in, nullptr, units, out);
@@ -537,8 +592,7 @@ int bx_conv_layer(bx_ctx* c, void* stream, int32_t net, int32_t layer, const flo
 int bx_mutual(bx_ctx* c, void* stream, const float* src_des, int32_t ns, const float* tgt_des, int32_t nt, int32_t* s_mids,
               int32_t* t_mids, int32_t* count_out)
 {
-    int rc;
-    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    BX_ENTER(c, false);
     if (ns > c->p.num_fps || nt > c->p.num_fps) { bx_set_error("bx_mutual: more descriptors than num_fps"); return BX_ERR_ARG; }
     c->skip = nullptr;
     return bxk_mutual(c, (hipStream_t)stream, src_des, ns, tgt_des, nt, s_mids, t_mids, count_out);
@@ -547,8 +601,7 @@ int bx_mutual(bx_ctx* c, void* stream, const float* src_des, int32_t ns, const f
 int bx_pose_net(bx_ctx* c, void* stream, const float* s_equi, const float* t_equi, const int32_t* s_mids, const int32_t* t_mids,
                 const int32_t* m_dev, int32_t max_m, float* ind_out, float* logits_out)
 {
-    int rc;
-    if ((rc = check_ctx(c, true)) != BX_OK) return rc;
+    BX_ENTER(c, true);
     if (max_m > c->p.num_fps) { bx_set_error("bx_pose_net: max_m exceeds num_fps"); return BX_ERR_ARG; }
     c->skip = nullptr;
     return pose_stack(c, (hipStream_t)stream, s_equi, t_equi, s_mids, t_mids, m_dev, max_m, ind_out, logits_out);
@@ -558,8 +611,7 @@ int bx_hypotheses(bx_ctx* c, void* stream, const float* ind, const int32_t* s_mi
                   int32_t max_m, const float* s_R, const float* t_R, const float* s_kpts, const float* t_kpts, float* R_out,
                   float* t_out, float* ss_out, float* tt_out)
 {
-    int rc;
-    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    BX_ENTER(c, false);
     return bxk_hypotheses((hipStream_t)stream, ind, s_mids, t_mids, m_dev, max_m, s_R, t_R, s_kpts, t_kpts, R_out, t_out, ss_out,
                           tt_out, nullptr, nullptr);
 }
@@ -567,8 +619,7 @@ int bx_hypotheses(bx_ctx* c, void* stream, const float* ind, const int32_t* s_mi
 int bx_consensus(bx_ctx* c, void* stream, const float* R, const float* t, const float* ss, const float* tt, const int32_t* M_dev,
                  int32_t max_M, int32_t* inlier_out, int32_t* count_out, int32_t* best_out)
 {
-    int rc;
-    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    BX_ENTER(c, false);
     if (max_M > c->p.num_fps * c->p.num_scales) { bx_set_error("bx_consensus: max_M exceeds num_fps*num_scales"); return BX_ERR_ARG; }
     c->skip = nullptr;
     return bxk_consensus(c, (hipStream_t)stream, R, t, ss, tt, M_dev, max_M, inlier_out, count_out, best_out);
@@ -577,16 +628,14 @@ int bx_consensus(bx_ctx* c, void* stream, const float* R, const float* t, const 
 int bx_ransac(bx_ctx* c, void* stream, const float* ss, const float* tt, const int32_t* corr, const int32_t* C_dev, int32_t max_C,
               uint64_t seed, double* T_out, int32_t* info_out)
 {
-    int rc;
-    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    BX_ENTER(c, false);
     return bxk_ransac(c, (hipStream_t)stream, ss, tt, corr, C_dev, max_C, seed, T_out, info_out, nullptr);
 }
 
 int bx_refine(bx_ctx* c, void* stream, const float* ss, const float* tt, const int32_t* M_dev, int32_t max_M, float* T_io,
               int32_t* iters_out)
 {
-    int rc;
-    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    BX_ENTER(c, false);
     if (max_M > c->p.num_fps * c->p.num_scales) { bx_set_error("bx_refine: max_M exceeds num_fps*num_scales"); return BX_ERR_ARG; }
     return bxk_refine(c, (hipStream_t)stream, ss, tt, M_dev, max_M, T_io, iters_out);
 }
@@ -594,32 +643,27 @@ int bx_refine(bx_ctx* c, void* stream, const float* ss, const float* tt, const i
 // ------------------------------------------------------------------------------------------------ pre-processing
 int bx_pre_reserve(bx_ctx* c, int64_t max_points)
 {
-    int rc;
-    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
-    BX_HIP(hipSetDevice(c->device));
+    BX_ENTER(c, false);
     return bxk_pre_reserve(c, max_points);
 }
 
 int bx_pre_voxel_downsample(bx_ctx* c, void* stream, const float* pts, int32_t n, double voxel_size, float* out, int32_t* count_out)
 {
-    int rc;
-    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    BX_ENTER(c, false);
     if (!pts || !out || !count_out) { bx_set_error("bx_pre_voxel_downsample: null argument"); return BX_ERR_ARG; }
     return bxk_pre_voxel_downsample(c, (hipStream_t)stream, pts, n, voxel_size, out, count_out);
 }
 
 int bx_random_perm(bx_ctx* c, void* stream, int32_t n, uint64_t seed, int32_t* out)
 {
-    int rc;
-    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    BX_ENTER(c, false);
     if (!out || n < 0 || n > (1 << 30)) { bx_set_error("bx_random_perm: bad argument"); return BX_ERR_ARG; }
     return bxk_random_perm((hipStream_t)stream, n, seed, out);
 }
 
 int bx_pre_pca(bx_ctx* c, void* stream, const float* pts, int32_t n, const int32_t* sample_idx, int32_t ns, double* out17)
 {
-    int rc;
-    if ((rc = check_ctx(c, false)) != BX_OK) return rc;
+    BX_ENTER(c, false);
     if (!pts || !sample_idx || !out17) { bx_set_error("bx_pre_pca: null argument"); return BX_ERR_ARG; }
     return bxk_pre_pca(c, (hipStream_t)stream, pts, n, sample_idx, ns, out17);
 }
@@ -674,8 +718,7 @@ struct LaneScope {   // section of a pair that takes its turn on the lane
 int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, const float* tgt, int32_t n_tgt, int32_t aligned_z,
                      const int32_t* perm_src, const int32_t* perm_tgt, uint64_t seed, bx_result* result)
 {
-    int rc;
-    if ((rc = check_ctx(c, true)) != BX_OK) return rc;
+    BX_ENTER(c, true);
     if (!src || !tgt || !perm_src || !perm_tgt || !result) { bx_set_error("bx_register_pair: null argument"); return BX_ERR_ARG; }
     const bx_params& p = c->p;
     if (n_src < 1 || n_tgt < 1 || n_src > p.max_points || n_tgt > p.max_points) {
@@ -712,13 +755,27 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
     for (int i = 0; i < S; ++i) {
         c->skip = (early && i > 0) ? &st->done : nullptr;
         { ProfScope ps(c, s, 1); if ((rc = bxk_radius_bisect(c, s, (int64_t)ns[big], NK, p.search_radius_thresholds[i], &st->des_r[i])) != BX_OK) return rc; }
+        const bool capi = c->cap_on && c->cap.scale == i;
         for (int cl = 0; cl < 2; ++cl) {
+            const bool capc = capi && c->cap.cloud == cl;
             { ProfScope ps(c, s, 11); if ((rc = bx_permute_launch(s, clouds[cl], perms[cl] + (size_t)i * ns[cl], ns[cl], c->pts_perm, c->skip)) != BX_OK) return rc; }
             // expected neighbourhood = threshold % of the cloud: large ones get 4 waves per keypoint, small ones 2 (measured)
             c->ball_waves_hint = p.search_radius_thresholds[i] >= 1.5 ? 4 : 2;
-            { ProfScope ps(c, s, 2); if ((rc = bxk_ball_group(c, s, c->pts_perm, ns[cl], c->kpts[cl], K, &st->des_r[i], P, c->ball_idx, c->patches)) != BX_OK) return rc; }
+            // the whole-pair path does not need the ball_query index list (nothing downstream reads it): idx_out = nullptr
+            { ProfScope ps(c, s, 2); if ((rc = bxk_ball_group(c, s, c->pts_perm, ns[cl], c->kpts[cl], K, &st->des_r[i], P, nullptr, c->patches)) != BX_OK) return rc; }
             { ProfScope ps(c, s, 3); if ((rc = bxk_patch_features(c, s, c->patches, K, P, &st->des_r[i], aligned_z, c->Rpatch[cl], c->feat)) != BX_OK) return rc; }
-            { LaneScope ls(c, s, 2); ProfScope ps(c, s, 4); if ((rc = desc_stack(c, s, c->feat, K, c->desc_out[cl], c->equi[cl], nullptr)) != BX_OK) return rc; }
+            if (capc) {
+                if ((rc = cap_copy(s, c->cap.pts_perm, c->pts_perm, (size_t)ns[cl] * 3)) != BX_OK) return rc;
+                if ((rc = cap_copy(s, c->cap.patches, c->patches, (size_t)K * P * 3)) != BX_OK) return rc;
+                if ((rc = cap_copy(s, c->cap.feat, c->feat, (size_t)K * BX_RAD * BX_EA * 16)) != BX_OK) return rc;
+            }
+            { LaneScope ls(c, s, 2); ProfScope ps(c, s, 4); if ((rc = desc_stack(c, s, c->feat, K, c->desc_out[cl], c->equi[cl], capc ? c->cap.x : nullptr)) != BX_OK) return rc; }
+            if (capi) {
+                if ((rc = cap_copy(s, c->cap.kpts[cl], c->kpts[cl], (size_t)K * 3)) != BX_OK) return rc;
+                if ((rc = cap_copy(s, c->cap.desc[cl], c->desc_out[cl], (size_t)K * 32)) != BX_OK) return rc;
+                if ((rc = cap_copy(s, c->cap.equi[cl], c->equi[cl], (size_t)K * BX_EA * 32)) != BX_OK) return rc;
+                if ((rc = cap_copy(s, c->cap.R[cl], c->Rpatch[cl], (size_t)K * 9)) != BX_OK) return rc;
+            }
         }
         { ProfScope ps(c, s, 6); if ((rc = bxk_mutual(c, s, c->desc_out[0], K, c->desc_out[1], K, c->s_mids, c->t_mids, &st->m_scale)) != BX_OK) return rc; }
         { LaneScope ls(c, s, 2); ProfScope ps(c, s, 7); if ((rc = pose_stack(c, s, c->equi[0], c->equi[1], c->s_mids, c->t_mids, &st->m_scale, K, c->ind, nullptr)) != BX_OK) return rc; }
@@ -726,6 +783,19 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
                                  c->R_cat, c->t_cat, c->ss_cat, c->tt_cat, &st->M, c->skip)) != BX_OK) return rc;
         hipLaunchKernelGGL(accumulate_kernel, dim3(1), dim3(64), 0, s, st, i, c->skip);
         { ProfScope ps(c, s, 8); if ((rc = bxk_consensus(c, s, c->R_cat, c->t_cat, c->ss_cat, c->tt_cat, &st->M, (i + 1) * K, c->inlier_ind, &st->C, &st->best)) != BX_OK) return rc; }
+        if (capi) {
+            const size_t MK = (size_t)(i + 1) * K;
+            if ((rc = cap_copy(s, c->cap.s_mids, c->s_mids, (size_t)K)) != BX_OK) return rc;
+            if ((rc = cap_copy(s, c->cap.t_mids, c->t_mids, (size_t)K)) != BX_OK) return rc;
+            if ((rc = cap_copy(s, c->cap.ind, c->ind, (size_t)K)) != BX_OK) return rc;
+            if ((rc = cap_copy(s, c->cap.R_cat, c->R_cat, MK * 9)) != BX_OK) return rc;
+            if ((rc = cap_copy(s, c->cap.t_cat, c->t_cat, MK * 3)) != BX_OK) return rc;
+            if ((rc = cap_copy(s, c->cap.ss_cat, c->ss_cat, MK * 3)) != BX_OK) return rc;
+            if ((rc = cap_copy(s, c->cap.tt_cat, c->tt_cat, MK * 3)) != BX_OK) return rc;
+            if ((rc = cap_copy(s, c->cap.cons_cnt, c->cons_cnt, MK)) != BX_OK) return rc;
+            if ((rc = cap_copy(s, c->cap.inlier_ind, c->inlier_ind, MK)) != BX_OK) return rc;
+            if (c->cap.counts) hipLaunchKernelGGL(cap_counts_kernel, dim3(1), dim3(64), 0, s, st, c->cap.counts, (double*)nullptr);
+        }
         if (early && i == 0) {
             if ((rc = bxk_ransac(c, s, c->ss_cat, c->tt_cat, c->inlier_ind, &st->C, K, bx_mix64(seed, 0x5AC0000ULL + ransac_calls), nullptr, nullptr, nullptr)) != BX_OK) return rc;
             ++ransac_calls;
@@ -737,6 +807,7 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
     if ((rc = bxk_ransac(c, s, c->ss_cat, c->tt_cat, c->inlier_ind, &st->C, S * K, bx_mix64(seed, 0x5AC0000ULL + ransac_calls), nullptr, nullptr,
                          early ? &st->done : nullptr)) != BX_OK) return rc; }
     c->skip = nullptr;
+    if (c->cap_on && c->cap.T_ransac) hipLaunchKernelGGL(cap_counts_kernel, dim3(1), dim3(64), 0, s, st, (int32_t*)nullptr, c->cap.T_ransac);
     if (p.pose_refine) {
         hipLaunchKernelGGL(pose_to_float_kernel, dim3(1), dim3(64), 0, s, st);
         { ProfScope ps(c, s, 10); if ((rc = bxk_refine(c, s, c->ss_cat, c->tt_cat, &st->M, S * K, st->Tf, &st->refine_iters)) != BX_OK) return rc; }

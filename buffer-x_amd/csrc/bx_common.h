@@ -20,6 +20,21 @@ void bx_set_error(const char* fmt, ...);
     } while (0)
 #define BX_LAUNCH_CHECK() BX_HIP(hipGetLastError())
 
+// Every entry point that launches work or allocates makes its device current for the calling thread and restores the previous
+// one on return: contexts on several devices may be driven from one thread (or one device from nn.DataParallel's replica
+// threads, whose current device is not ours).
+struct BxDevScope {
+    int prev = -1; bool switched = false;
+    explicit BxDevScope(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~BxDevScope() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
+    BxDevScope(const BxDevScope&) = delete;
+    BxDevScope& operator=(const BxDevScope&) = delete;
+};
+
 // ------------------------------------------------------------------ geometry constants
 constexpr int BX_RAD = 3, BX_ELE = 7, BX_AZI = 20;
 constexpr int BX_EA = BX_ELE * BX_AZI;          // 140 positions of the cylindrical map
@@ -143,6 +158,10 @@ struct bx_ctx {
     const int32_t* skip;                // device flag: non-zero => pipeline kernels return immediately (early exit)
     struct bx_lane* lane;               // optional: orders the MFMA-heavy sections of the pairs of several contexts (bx_attach_lane)
     void* pre;                          // bx_pre_ws* (k_pre.hip): workspace of the pre-processing entry points, reserved on demand
+    int conv_cap[2][BX_NPOSE];          // persistent-grid size of every conv layer on THIS device (0 = not set up yet)
+    int conv_persist, conv_cap_override, n_cu;
+    bx_capture cap;                     // bx_set_capture: intermediates of one scale copied to caller buffers
+    int cap_on;
     int prof_on;
     void* prof;                         // std::vector<ProfEvt>* (bx_api.hip)
 };

@@ -491,8 +491,8 @@ __global__ __launch_bounds__(CT, 3) void cost_l1_kernel(const float* __restrict_
 }
 
 template <int NCHUNK, int NTAPS, int P_IN, int P_LDS, int P_OUT, int COUT, int G, bool RELU, int NW = 8, int NPW = 1>
-int launch_conv(hipStream_t s, const ConvLayerDev& L, const float* in, const int32_t* units_dev, int max_units, float* out,
-                const int32_t* skip, long long* dbg = nullptr)
+int launch_conv(bx_ctx* c, int net, int layer, hipStream_t s, const ConvLayerDev& L, const float* in, const int32_t* units_dev, int max_units,
+                float* out, const int32_t* skip, long long* dbg = nullptr)
 {
     using C = ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT, COUT, G, RELU, NW, NPW>;
     constexpr int CT = C::CT;
@@ -502,27 +502,23 @@ int launch_conv(hipStream_t s, const ConvLayerDev& L, const float* in, const int
         return BX_ERR_STATE;
     }
     auto k = conv_kernel<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT, COUT, G, RELU, NW, NPW>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // Function attribute and occupancy are per DEVICE: they are kept in the context (one context = one device), not in
+    // process-wide statics, so contexts on several devices of one process each set them up for their own device.
+    int& cap = c->conv_cap[net][layer];
+    if (cap == 0) {
         BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
-        attr_set = true;
+        // persistent workgroups: as many as are co-resident, each walking its unit groups (BX_CONV_PERSIST=0: one group each;
+        // BX_CONV_PERSIST_CAP=n: at most n workgroups -- test hook that forces the group walk at small unit counts)
+        cap = 1 << 30;
+        if (c->conv_persist) {
+            int occ = 0;
+            BX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, CT, C::LDS_BYTES));
+            if (occ >= 1) cap = occ * c->n_cu;
+            if (c->conv_cap_override > 0 && c->conv_cap_override < cap) cap = c->conv_cap_override;
+        }
     }
     int grid = (max_units + G - 1) / G;
     if (grid <= 0) return BX_OK;
-    // persistent workgroups: as many as are co-resident, each walking its unit groups (BX_CONV_PERSIST=0: one group each)
-    static int cap = -1;
-    if (cap < 0) {
-        cap = 1 << 30;
-        const char* e = getenv("BX_CONV_PERSIST");
-        if (!e || atoi(e) != 0) {
-            int dev = 0, occ = 0;
-            hipDeviceProp_t prop;
-            BX_HIP(hipGetDevice(&dev));
-            BX_HIP(hipGetDeviceProperties(&prop, dev));
-            BX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, CT, C::LDS_BYTES));
-            if (occ >= 1) cap = occ * prop.multiProcessorCount;
-        }
-    }
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(k, dim3(grid), dim3(CT), C::LDS_BYTES, s, in, units_dev, max_units, L.W, L.b, L.lrow, L.lrow2, L.obase, L.toff,
                        out, skip, dbg);
@@ -544,28 +540,28 @@ int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, cons
         // changes nothing, so the LDS read rate is not what holds the stack at 0.81 of the f32 MFMA peak.
         switch (layer) {
             //                     NCHUNK taps P_IN P_LDS P_OUT COUT G  RELU
-            case 0: return launch_conv<3, 9, 140, CYL, 140, 64, 2, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 1: return launch_conv<4, 9, 140, CYL, 140, 64, 2, true>(s, L, in, units_dev, max_units, out, c->skip,
+            case 0: return launch_conv<3, 9, 140, CYL, 140, 64, 2, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
+            case 1: return launch_conv<4, 9, 140, CYL, 140, 64, 2, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip,
                                                                           getenv("BX_BALL_DEBUG") ? c->ball_dbg : nullptr);
-            case 2: return launch_conv<4, 9, 140, CYL, 140, 128, 1, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 3: return launch_conv<8, 9, 140, CYL, 140, 128, 1, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 4: return launch_conv<8, 9, 140, CYL, 140, 64, 2, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 5: return launch_conv<4, 9, 140, CYL, 140, 64, 2, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 6: return launch_conv<4, 9, 140, CYL, 140, 32, 2, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 7: return launch_conv<2, 9, 140, CYL, 140, 32, 2, false>(s, L, in, units_dev, max_units, out, c->skip);
+            case 2: return launch_conv<4, 9, 140, CYL, 140, 128, 1, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
+            case 3: return launch_conv<8, 9, 140, CYL, 140, 128, 1, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
+            case 4: return launch_conv<8, 9, 140, CYL, 140, 64, 2, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
+            case 5: return launch_conv<4, 9, 140, CYL, 140, 64, 2, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
+            case 6: return launch_conv<4, 9, 140, CYL, 140, 32, 2, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
+            case 7: return launch_conv<2, 9, 140, CYL, 140, 32, 2, false>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
         }
     } else if (net == 1) {
         const ConvLayerDev& L = c->pose[layer];
         switch (layer) {
-            case 1: return launch_conv<2, 27, 972, 972, 256, 64, 1, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 2: return launch_conv<4, 9, 256, 256, 196, 64, 2, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 3: return launch_conv<4, 9, 196, 196, 144, 128, 2, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 4: return launch_conv<8, 9, 144, 144, 100, 128, 2, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 5: return launch_conv<8, 9, 100, 100, 64, 64, 4, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 6: return launch_conv<4, 9, 64, 64, 36, 64, 8, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 7: return launch_conv<4, 9, 36, 36, 16, 32, 16, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 8: return launch_conv<2, 9, 16, 16, 4, 32, 32, true>(s, L, in, units_dev, max_units, out, c->skip);
-            case 9: return launch_conv<2, 4, 4, 4, 1, 20, 128, false>(s, L, in, units_dev, max_units, out, c->skip);
+            case 1: return launch_conv<2, 27, 972, 972, 256, 64, 1, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
+            case 2: return launch_conv<4, 9, 256, 256, 196, 64, 2, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
+            case 3: return launch_conv<4, 9, 196, 196, 144, 128, 2, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
+            case 4: return launch_conv<8, 9, 144, 144, 100, 128, 2, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
+            case 5: return launch_conv<8, 9, 100, 100, 64, 64, 4, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
+            case 6: return launch_conv<4, 9, 64, 64, 36, 64, 8, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
+            case 7: return launch_conv<4, 9, 36, 36, 16, 32, 16, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
+            case 8: return launch_conv<2, 9, 16, 16, 4, 32, 32, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
+            case 9: return launch_conv<2, 4, 4, 4, 1, 20, 128, false>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
         }
     }
     bx_set_error("bxk_conv: bad net/layer %d/%d", net, layer);

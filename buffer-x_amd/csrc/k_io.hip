@@ -163,6 +163,11 @@ int read_ply(const FileBuf& fb, const char* path, float* out, int64_t cap, int64
     const bool swap = fmt == 2;
     for (int ei = 0; ei <= vi; ++ei) {
         const PlyElem& e = elems[ei];
+        // every row of a non-empty element occupies at least one byte of the body (a line feed / one scalar)
+        if (!e.props.empty() && e.count > (int64_t)(fb.d.size() - pos)) {
+            bx_set_error("bx_io: %s: element '%s' declares %lld rows, %lld bytes remain", path, e.name.c_str(), (long long)e.count, (long long)(fb.d.size() - pos));
+            return BX_ERR_ARG;
+        }
         int ix[3] = {-1, -1, -1};
         bool has_list = false;
         for (size_t k = 0; k < e.props.size(); ++k) {
@@ -181,8 +186,19 @@ int read_ply(const FileBuf& fb, const char* path, float* out, int64_t cap, int64
                 char* endp = nullptr;
                 for (size_t k = 0; k < e.props.size(); ++k) {
                     if (e.props[k].is_list) {
-                        const long cnt = strtol(p, &endp, 10); p = endp;
-                        for (long q = 0; q < cnt; ++q) { (void)strtod(p, &endp); p = endp; }
+                        // the per-row list length comes from the file: a value is at least two characters ("0 "), so a count
+                        // that the rest of the line cannot hold is corrupt (and would otherwise spin for up to 2^63 iterations)
+                        const long cnt = strtol(p, &endp, 10);
+                        if (endp == p || cnt < 0 || (size_t)cnt > (size_t)(line.c_str() + line.size() - endp)) {
+                            bx_set_error("bx_io: %s: bad list length on vertex line %lld", path, (long long)r);
+                            return BX_ERR_ARG;
+                        }
+                        p = endp;
+                        for (long q = 0; q < cnt; ++q) {
+                            (void)strtod(p, &endp);
+                            if (endp == p) { bx_set_error("bx_io: %s: short list on vertex line %lld", path, (long long)r); return BX_ERR_ARG; }
+                            p = endp;
+                        }
                         continue;
                     }
                     const double v = strtod(p, &endp);
@@ -221,8 +237,14 @@ int read_ply(const FileBuf& fb, const char* path, float* out, int64_t cap, int64
                     const PlyProp& pr = e.props[k];
                     if (pr.is_list) {
                         if (pos + (size_t)scalar_size(pr.count_t) > fb.d.size()) { bx_set_error("bx_io: %s: truncated PLY body", path); return BX_ERR_ARG; }
-                        const long cnt = (long)load_scalar(fb.d.data() + pos, pr.count_t, swap);
-                        pos += (size_t)scalar_size(pr.count_t) + (size_t)cnt * (size_t)scalar_size(pr.t);
+                        const double cntf = load_scalar(fb.d.data() + pos, pr.count_t, swap);
+                        const size_t left = fb.d.size() - pos - (size_t)scalar_size(pr.count_t);
+                        // a negative count would move pos backwards, a huge one wrap it: both are corrupt files
+                        if (!(cntf >= 0.0) || cntf > (double)(left / (size_t)scalar_size(pr.t))) {
+                            bx_set_error("bx_io: %s: bad list length in element '%s' row %lld", path, e.name.c_str(), (long long)r);
+                            return BX_ERR_ARG;
+                        }
+                        pos += (size_t)scalar_size(pr.count_t) + (size_t)cntf * (size_t)scalar_size(pr.t);
                     } else {
                         if (pos + (size_t)scalar_size(pr.t) > fb.d.size()) { bx_set_error("bx_io: %s: truncated PLY body", path); return BX_ERR_ARG; }
                         if (want) for (int c = 0; c < 3; ++c) if (ix[c] == (int)k) out[r * 3 + c] = (float)load_scalar(fb.d.data() + pos, pr.t, swap);
@@ -489,7 +511,7 @@ int bx_io_read_xyz(const char* path, float* xyz_out, int64_t capacity, int64_t* 
 int bx_prefetch_create(int32_t device, int32_t slots, int64_t max_points, bx_prefetch** out)
 {
     if (!out || slots < 1 || slots > 64 || max_points < 1) { bx_set_error("bx_prefetch_create: bad argument"); return BX_ERR_ARG; }
-    BX_HIP(hipSetDevice(device));
+    BxDevScope ds(device);
     bx_prefetch* p = new bx_prefetch();
     p->device = device; p->max_points = max_points;
     p->slots.resize((size_t)slots);
@@ -573,7 +595,7 @@ int bx_prefetch_destroy(bx_prefetch* p)
     }
     p->cv_work.notify_all();
     if (p->worker.joinable()) p->worker.join();
-    (void)hipSetDevice(p->device);
+    BxDevScope ds(p->device);
     (void)hipStreamSynchronize(p->copy_stream);
     for (auto& s : p->slots) {
         if (s.consumed_valid) (void)hipEventSynchronize(s.consumed);

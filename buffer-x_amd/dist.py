@@ -1,9 +1,15 @@
 """Multi-GPU plan: pairs are independent units (reference test.py:132-146 carries no state between pairs), so
-ranks take pairs round-robin and the ONLY collective is one all-gather of a fixed 72-byte record per pair at
-the end (RCCL over xGMI when backend == "nccl"; gloo on CPU for the tests).  SURVEY.md §8e."""
+ranks take pairs round-robin and the ONLY collective is one all-gather of a fixed-size record per pair at
+the end (RCCL over xGMI when backend == "nccl"; gloo on CPU for the tests).  SURVEY.md §8e.
+
+The record is float64 (192 bytes per pair: 3 404 pairs of 3DMatch + 3DLoMatch = 654 KB, still one latency-bound collective): an
+un-refined RANSAC pose is binary64 (every outdoor configuration), so a float32 record would change its last bits when it crosses
+ranks and a sharded run would not be bit-identical to a single-GPU run.  buffer-x_amd/evaluate.py's state rows are float64 for the
+same reason; both travel through gather_rows()."""
 import numpy as np
 
-RECORD = 18  # float32: pair_id, R[9], t[3], num_inliers, num_mutual, num_inlier_ind, scales_used, model_ms  (72 B)
+# float64: pair_id, pose[16] row-major, num_inliers, num_mutual, num_inlier_ind, scales_used, ransac_iters, model_ms, pose dtype (32 / 64)
+RECORD = 24
 
 
 def shard_indices(n_pairs, rank, world):
@@ -11,23 +17,23 @@ def shard_indices(n_pairs, rank, world):
     return list(range(rank, n_pairs, world))
 
 
-def pack_record(pair_id, pose, num_inliers, num_mutual, num_inlier_ind, scales_used, model_ms):
-    r = np.zeros(RECORD, np.float32)
-    pose = np.asarray(pose, np.float64).reshape(4, 4)
+def pack_record(pair_id, pose, num_inliers, num_mutual, num_inlier_ind, scales_used, model_ms, ransac_iters=0):
+    r = np.zeros(RECORD, np.float64)
+    pose = np.asarray(pose)
+    r[23] = 32 if pose.dtype == np.float32 else 64
     r[0] = pair_id
-    r[1:10] = pose[:3, :3].reshape(-1)
-    r[10:13] = pose[:3, 3]
-    r[13:17] = [num_inliers, num_mutual, num_inlier_ind, scales_used]
-    r[17] = model_ms
+    r[1:17] = pose.astype(np.float64).reshape(-1)
+    r[17:22] = [num_inliers, num_mutual, num_inlier_ind, scales_used, ransac_iters]
+    r[22] = model_ms
     return r
 
 
 def unpack_record(r):
-    T = np.eye(4)
-    T[:3, :3] = np.asarray(r[1:10], np.float64).reshape(3, 3)
-    T[:3, 3] = r[10:13]
-    return dict(pair_id=int(r[0]), pose=T, num_inliers=int(r[13]), num_mutual=int(r[14]), num_inlier_ind=int(r[15]),
-                scales_used=int(r[16]), model_ms=float(r[17]))
+    T = np.asarray(r[1:17], np.float64).reshape(4, 4).copy()
+    if r[23] == 32:
+        T = T.astype(np.float32)
+    return dict(pair_id=int(r[0]), pose=T, num_inliers=int(r[17]), num_mutual=int(r[18]), num_inlier_ind=int(r[19]),
+                scales_used=int(r[20]), ransac_iters=int(r[21]), model_ms=float(r[22]))
 
 
 def gather_rows(local, n_rows, device=None):
@@ -55,5 +61,5 @@ def gather_rows(local, n_rows, device=None):
 
 
 def gather_records(local, n_pairs, device=None):
-    """local: float32 [n_local, RECORD] of this rank's pairs -> float32 [n_pairs, RECORD] ordered by pair id on every rank."""
-    return gather_rows(np.asarray(local, np.float32).reshape(-1, RECORD), n_pairs, device)
+    """local: float64 [n_local, RECORD] of this rank's pairs -> float64 [n_pairs, RECORD] ordered by pair id on every rank."""
+    return gather_rows(np.asarray(local, np.float64).reshape(-1, RECORD), n_pairs, device)

@@ -39,7 +39,18 @@ class BxResult(C.Structure):
                 ("des_r", C.c_float * BX_MAX_SCALES)]
 
 
+class BxCapture(C.Structure):
+    """include/bufferx.h bx_capture: caller-owned device buffers that receive the intermediates of one scale."""
+    _fields_ = [("scale", C.c_int32), ("cloud", C.c_int32), ("pts_perm", C.c_void_p), ("patches", C.c_void_p),
+                ("feat", C.c_void_p), ("x", C.c_void_p), ("kpts", C.c_void_p * 2), ("desc", C.c_void_p * 2),
+                ("equi", C.c_void_p * 2), ("R", C.c_void_p * 2), ("s_mids", C.c_void_p), ("t_mids", C.c_void_p),
+                ("ind", C.c_void_p), ("R_cat", C.c_void_p), ("t_cat", C.c_void_p), ("ss_cat", C.c_void_p),
+                ("tt_cat", C.c_void_p), ("cons_cnt", C.c_void_p), ("inlier_ind", C.c_void_p), ("counts", C.c_void_p),
+                ("T_ransac", C.c_void_p)]
+
+
 EXPORTS = ["bx_create", "bx_destroy", "bx_last_error", "bx_load_weights", "bx_workspace_bytes", "bx_register_pair",
+           "bx_set_capture",
            "bx_profile_enable", "bx_profile_read", "bx_debug_read",
            "bx_fps", "bx_radius", "bx_permute", "bx_ball_group", "bx_patch_features", "bx_desc_net", "bx_conv_layer",
            "bx_mutual", "bx_pose_net", "bx_hypotheses", "bx_consensus", "bx_ransac", "bx_refine",
@@ -395,6 +406,36 @@ class Context:
         _chk(self.lib.bx_refine(self.handle, self._stream(), self._p(ss), self._p(tt), self._p(M_dev), C.c_int32(max_M),
                                 self._p(T), self._p(it)), "bx_refine")
         return T, it
+
+    def set_capture(self, scale, cloud, n_points):
+        """Allocate capture buffers for (scale, cloud) and arm bx_set_capture; returns {name: device tensor}.
+        n_points = size of the captured cloud.  set_capture(None, ...) disarms."""
+        t = self.torch
+        if scale is None:
+            _chk(self.lib.bx_set_capture(self.handle, None), "bx_set_capture")
+            self._cap = None
+            return None
+        K, P, S = self.params.num_fps, self.params.num_points_per_patch, self.params.num_scales
+        f32, i32 = t.float32, t.int32
+        z = lambda shape, dt: t.zeros(shape, dtype=dt, device=f"cuda:{self.device}")
+        buf = dict(pts_perm=z((n_points, 3), f32), patches=z((K, P, 3), f32), feat=z((K, 3, 140, 16), f32),
+                   x=z((K, 2, 140, 16), f32), kpts=[z((K, 3), f32) for _ in range(2)], desc=[z((K, 32), f32) for _ in range(2)],
+                   equi=[z((K, 140, 32), f32) for _ in range(2)], R=[z((K, 9), f32) for _ in range(2)],
+                   s_mids=z((K,), i32), t_mids=z((K,), i32), ind=z((K,), f32), R_cat=z((S * K, 9), f32),
+                   t_cat=z((S * K, 3), f32), ss_cat=z((S * K, 3), f32), tt_cat=z((S * K, 3), f32), cons_cnt=z((S * K,), i32),
+                   inlier_ind=z((S * K,), i32), counts=z((4,), i32), T_ransac=z((16,), t.float64))
+        cap = BxCapture()
+        cap.scale, cap.cloud = int(scale), int(cloud)
+        for k, v in buf.items():
+            if isinstance(v, list):
+                arr = getattr(cap, k)
+                for j, tv in enumerate(v):
+                    arr[j] = tv.data_ptr()
+            else:
+                setattr(cap, k, v.data_ptr())
+        _chk(self.lib.bx_set_capture(self.handle, C.byref(cap)), "bx_set_capture")
+        self._cap = buf
+        return buf
 
     def new_result(self):
         """BxResult living in pinned host memory (so the final D2H copy is truly asynchronous)."""

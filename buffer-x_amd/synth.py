@@ -54,9 +54,10 @@ def indoor_scene(rng, n_raw, extent=(3.0, 3.0, 2.5), n_boxes=8):
     return np.concatenate(parts)
 
 
-def outdoor_scene(rng, rings=64, az_steps=2048, max_range=80.0, n_boxes=40, sensor_h=1.73):
+def outdoor_scene(rng, rings=64, az_steps=2048, max_range=80.0, n_boxes=40, sensor_h=1.73, box_range=(6.0, 60.0), box_size=(1.5, 12.0, 9.0),
+                  elev_deg=(-24.8, 2.0), return_rings=False):
     """LiDAR-like sweep: ring pattern over a ground plane and vertical boxes (buildings, cars)."""
-    elev = np.deg2rad(np.linspace(-24.8, 2.0, rings))
+    elev = np.deg2rad(np.linspace(elev_deg[0], elev_deg[1], rings))
     az = np.linspace(0, 2 * np.pi, az_steps, endpoint=False)
     E, A = np.meshgrid(elev, az, indexing="ij")
     d = np.stack([np.cos(E) * np.cos(A), np.cos(E) * np.sin(A), np.sin(E)], -1).reshape(-1, 3)
@@ -65,8 +66,8 @@ def outdoor_scene(rng, rings=64, az_steps=2048, max_range=80.0, n_boxes=40, sens
     t[down] = -sensor_h / -d[down, 2] * -1.0
     t[down] = sensor_h / (-d[down, 2])
     for _ in range(n_boxes):
-        size = np.array([rng.uniform(1.5, 12), rng.uniform(1.5, 12), rng.uniform(1.4, 9)])
-        r = rng.uniform(6, 60)
+        size = np.array([rng.uniform(box_size[0], box_size[1]), rng.uniform(box_size[0], box_size[1]), rng.uniform(1.4, box_size[2])])
+        r = rng.uniform(box_range[0], box_range[1])
         th = rng.uniform(0, 2 * np.pi)
         c = np.array([r * np.cos(th), r * np.sin(th), -sensor_h + size[2] / 2])
         lo, hi = c - size / 2, c + size / 2
@@ -80,13 +81,46 @@ def outdoor_scene(rng, rings=64, az_steps=2048, max_range=80.0, n_boxes=40, sens
     ok = np.isfinite(t) & (t < max_range)
     pts = d[ok] * t[ok, None]
     pts += rng.normal(0, 0.01, pts.shape)
+    if return_rings:
+        return pts, (np.arange(len(d)) // az_steps)[ok]
     return pts
 
 
 def make_pair(seed, kind="indoor", n_target=30000, overlap=0.6, voxel=None, max_rot_deg=None, max_trans=None,
-              jitter=None, identical=False):
-    """Returns dict(src, tgt, T_gt (4x4 float64, src->tgt), aligned_z)."""
+              jitter=None, identical=False, shared=False):
+    """Returns dict(src, tgt, T_gt (4x4 float64, src->tgt), aligned_z).
+
+    shared=True (indoor): noise-free PARTIAL-overlap pair whose two fragments are crops of ONE voxelised sample of the scene,
+    shuffled independently: inside the overlap the surface samples coincide (tgt = fp32(R p + t)), outside they do not exist in
+    the other fragment.  Keypoints are chosen by each fragment's own FPS; the ones that coincide (about K^2/N of them) carry
+    identical neighbourhoods, which is what lets a randomly initialised network register the pair."""
     rng = np.random.default_rng(seed)
+    if shared:
+        assert kind == "indoor"
+        voxel = 0.025 if voxel is None else voxel
+        scene = _voxel_down(indoor_scene(rng, int(n_target * 4.5)), voxel, rng).astype(np.float64)
+        half = 1.5
+        a = half * overlap / (2.0 - overlap)
+        R = _rot(rng.normal(size=3), np.deg2rad(rng.uniform(10, 45 if max_rot_deg is None else max_rot_deg)))
+        t = rng.uniform(-1, 1, 3) * (0.8 if max_trans is None else max_trans)
+        off = np.array([0.3, -0.2, 1.6])
+        src = scene[scene[:, 0] < a] + off
+        tgt = (scene[scene[:, 0] > -a] + off) @ R.T + t
+        # thin both fragments to n_target points with ONE keep-mask over the scene, so that the overlap keeps coinciding samples
+        keep = rng.permutation(len(scene))
+        rank = np.empty(len(scene), np.int64)
+        rank[keep] = np.arange(len(scene))
+        rs, rt = rank[scene[:, 0] < a], rank[scene[:, 0] > -a]
+        m = max(len(src), len(tgt))
+        if n_target and m > n_target:
+            cut = int(len(scene) * n_target / m)
+            src, tgt = src[rs < cut], tgt[rt < cut]
+        src = src[rng.permutation(len(src))]
+        tgt = tgt[rng.permutation(len(tgt))]
+        T = np.eye(4)
+        T[:3, :3] = R
+        T[:3, 3] = t
+        return dict(src=np.ascontiguousarray(src, np.float32), tgt=np.ascontiguousarray(tgt, np.float32), T_gt=T, aligned_z=False)
     if kind == "indoor":
         voxel = 0.025 if voxel is None else voxel
         jitter = 0.002 if jitter is None else jitter
@@ -138,6 +172,26 @@ def make_pair(seed, kind="indoor", n_target=30000, overlap=0.6, voxel=None, max_
     T[:3, 3] = t
     return dict(src=np.ascontiguousarray(src, np.float32), tgt=np.ascontiguousarray(tgt, np.float32), T_gt=T,
                 aligned_z=aligned)
+
+
+def make_tiers_pair(seed):
+    """TIERS_hetero-like pair (dense -> sparse LiDAR at indoor-scale range, z axes aligned): src = one 128-ring
+    sweep (~100k points, range <= 20 m), tgt = the 64 even rings of the SAME sweep seen from a displaced, yaw-rotated pose
+    (tgt = fp32(R p + t), noise-free), shuffled independently.  The samples of the sparse sensor coincide with samples of the dense
+    one, which is what lets randomly initialised weights find enough consistent matches for the early exit to be exercised."""
+    rng = np.random.default_rng(seed)
+    pts, ring = outdoor_scene(rng, rings=128, az_steps=1024, max_range=20.0, n_boxes=30, box_range=(2.5, 16.0), box_size=(0.6, 4.0, 3.0),
+                              elev_deg=(-45.0, 20.0), return_rings=True)
+    yaw = np.deg2rad(rng.uniform(-25, 25))
+    R = _rot([0, 0, 1], yaw)
+    t = np.array([rng.uniform(0.5, 2.0), rng.uniform(-0.5, 0.5), 0.0])
+    src = pts[rng.permutation(len(pts))]
+    sparse = pts[ring % 2 == 0]
+    tgt = (sparse @ R.T + t)[rng.permutation(len(sparse))]
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = t
+    return dict(src=np.ascontiguousarray(src, np.float32), tgt=np.ascontiguousarray(tgt, np.float32), T_gt=T, aligned_z=True)
 
 
 def pose_error(T_est, T_gt):

@@ -131,6 +131,33 @@ int bx_register_pair(bx_ctx *ctx, void *stream, const float *src, int32_t n_src,
                      int32_t aligned_z, const int32_t *perm_src, const int32_t *perm_tgt, uint64_t seed,
                      bx_result *result);
 
+/* ---- capture of intermediates (parity tests at sizes the CPU oracle cannot run end to end) ----------------------------------
+ * While a capture is set, bx_register_pair copies (stream-ordered, device to device) the intermediates of ONE scale into
+ * caller-owned device buffers; every pointer is nullable.  The per-cloud transients (permuted cloud, patches, voxel features,
+ * last conv map) are taken from cloud `cloud` (0 = src, 1 = tgt); the per-scale tensors from both clouds.  The cumulative tensors
+ * are copied right after the consensus step of scale `scale`.  T_ransac / T_final: the pose after the last RANSAC call and the
+ * returned pose.  A parity test feeds these tensors, a sampled subset at a time, to the oracle stage that consumes them.
+ * bx_set_capture(ctx, NULL) switches the capture off.  The struct is copied; the buffers must stay alive while it is set.      */
+typedef struct bx_capture {
+    int32_t scale, cloud;
+    float *pts_perm;                  /* [n][3]           permuted cloud (models/patch_embedder.py:96-97)                  */
+    float *patches;                   /* [K][P][3]        select_patches output                                             */
+    float *feat;                      /* [K][3][140][16]  pnt_layer + max (chunked)                                         */
+    float *x;                         /* [K][2][140][16]  Cylindrical_Net output (chunked)                                  */
+    float *kpts[2];                   /* [K][3]                                                                             */
+    float *desc[2];                   /* [K][32]                                                                            */
+    float *equi[2];                   /* [K][140][32]                                                                       */
+    float *R[2];                      /* [K][9]           patch rotations                                                   */
+    int32_t *s_mids, *t_mids;         /* [K]              mutual matches of the scale                                       */
+    float *ind;                       /* [K]              soft-argmax of CostNet                                            */
+    float *R_cat, *t_cat, *ss_cat, *tt_cat;   /* [S*K][9], [S*K][3] x3   accumulated hypotheses / matched keypoints        */
+    int32_t *cons_cnt;                /* [S*K]            inlier count of every hypothesis                                  */
+    int32_t *inlier_ind;              /* [S*K]                                                                              */
+    int32_t *counts;                  /* [4] = {m of the scale, M, C, best}                                                 */
+    double *T_ransac;                 /* [16]                                                                               */
+} bx_capture;
+int bx_set_capture(bx_ctx *ctx, const bx_capture *cap);
+
 /* ---- stage entry points (parity tests + operator-level drop-ins) ----------------------------- */
 
 /* pointnet2_ops.furthest_point_sample + gather_operation (models/BUFFERX.py:286-290,338-346).

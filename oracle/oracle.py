@@ -25,7 +25,9 @@ def build(force=False):
     if stale or force:
         subprocess.check_call(["make", "-C", _HERE, "_build/libbx_oracle.so"], stdout=subprocess.DEVNULL)
     ref_so = os.path.join(_HERE, "_ref", "libref_neighbors.so")
-    if os.path.isdir("/root/reference/cpp_wrappers") and (force or not os.path.exists(ref_so)):
+    shim = os.path.join(_HERE, "ref_neighbors_shim.cpp")
+    ref_stale = (not os.path.exists(ref_so)) or os.path.getmtime(shim) > os.path.getmtime(ref_so)
+    if os.path.isdir("/root/reference/cpp_wrappers") and (force or ref_stale):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
     return so
 
@@ -236,3 +238,16 @@ def ref_radius_neighbors(queries, supports, radius_, max_out):
     r.ref_radius_neighbors(_p(q), C.c_int(len(q)), _p(s), C.c_int(len(s)), C.c_float(radius_), _p(out), C.c_int(max_out),
                            _p(cnt))
     return out, cnt
+
+
+def ref_batch_neighbors(queries, supports, radius_):
+    """Reference call sequence of batch_nanoflann_neighbors (cpp_wrappers/cpp_neighbors/neighbors/neighbors.cpp:211-332) for one
+    cloud: KD-tree build + serial sorted radius search of every query + the dense padded index matrix.  -> (max_count, checksum)
+    or None when oracle/_ref is absent.  bench.py times this call (single thread, like the reference's float path)."""
+    r = ref_lib()
+    if r is None or not hasattr(r, "ref_batch_neighbors"):
+        return None
+    q, s = _f(queries), _f(supports)
+    cs = C.c_longlong(0)
+    mc = r.ref_batch_neighbors(_p(q), C.c_int(len(q)), _p(s), C.c_int(len(s)), C.c_float(radius_), C.byref(cs))
+    return int(mc), int(cs.value)

@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the multi-GPU plan: round-robin pair sharding + ONE all-gather of 72-byte records."""
+"""world_size-2 gloo test of the multi-GPU plan: round-robin pair sharding + ONE all-gather of fixed-size float64 records."""
 import os
 import subprocess
 import sys
@@ -17,14 +17,15 @@ n_pairs = 7
 mine = D.shard_indices(n_pairs, rank, world)
 recs = []
 for i in mine:
-    T = np.eye(4); T[:3, 3] = [i, 2 * i, 3 * i]; T[0, 1] = 0.5 * i
+    T = np.eye(4); T[:3, 3] = [i, 2 * i, 3 * i]; T[0, 1] = 0.5 * i + 1e-13 / 3
     recs.append(D.pack_record(i, T, 10 + i, 100 + i, 50 + i, 3, 1.5 * i))
-allr = D.gather_records(np.stack(recs) if recs else np.zeros((0, D.RECORD), np.float32), n_pairs)
+allr = D.gather_records(np.stack(recs) if recs else np.zeros((0, D.RECORD), np.float64), n_pairs)
 assert allr.shape == (n_pairs, D.RECORD), allr.shape
 for i in range(n_pairs):
     u = D.unpack_record(allr[i])
     assert u["pair_id"] == i and u["num_inliers"] == 10 + i and u["num_mutual"] == 100 + i
-    assert np.allclose(u["pose"][:3, 3], [i, 2 * i, 3 * i]) and u["scales_used"] == 3
+    assert np.array_equal(u["pose"][:3, 3], [i, 2 * i, 3 * i]) and u["scales_used"] == 3
+    assert u["pose"].dtype == np.float64 and u["pose"][0, 1] == 0.5 * i + 1e-13 / 3      # binary64 survives the collective
 sys.stdout.write(f"rank{rank}ok{len(mine)}\n"); sys.stdout.flush()
 dist.destroy_process_group()
 '''
@@ -47,5 +48,8 @@ def test_shard_covers_all_pairs_once():
         for w in (1, 2, 8):
             got = sorted(i for r in range(w) for i in D.shard_indices(n, r, w))
             assert got == list(range(n))
-    r = D.pack_record(5, np.eye(4), 1, 2, 3, 4, 6.5)
-    assert r.nbytes == 72 and D.unpack_record(r)["model_ms"] == 6.5
+    r = D.pack_record(5, np.eye(4), 1, 2, 3, 4, 6.5, 77)
+    u = D.unpack_record(r)
+    assert r.nbytes == 8 * D.RECORD and u["model_ms"] == 6.5 and u["ransac_iters"] == 77 and u["pose"].dtype == np.float64
+    u32 = D.unpack_record(D.pack_record(5, np.eye(4, dtype=np.float32), 1, 2, 3, 4, 6.5))
+    assert u32["pose"].dtype == np.float32

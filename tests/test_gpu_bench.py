@@ -1,0 +1,44 @@
+"""bench.py on the GPU box: the multi-rank code path (pair sharding + the ONE all-gather of float64 records) must give records
+that are bit-identical to a single-rank run of the same pairs, and `python bench.py --gpus N` must start its own ranks when no
+launcher set WORLD_SIZE.  Both ranks share the single GPU of the test box (BX_BENCH_SAME_GPU=1, gloo collectives)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--num-fps", "256", "--ppp", "128", "--scales", "2", "--distinct", "3", "--inflight", "2", "--warmup", "1", "--no-cpu-baseline"]
+
+
+def _run(cmd, env_extra, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_world2_records_equal_world1(tmp_path):
+    r1, r2, r3 = str(tmp_path / "w1.npy"), str(tmp_path / "w2.npy"), str(tmp_path / "w2s.npy")
+    j1 = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "6", "--dump-records", r1] + SMALL, {})
+    test_env = {"BX_DIST_BACKEND": "gloo", "BX_BENCH_SAME_GPU": "1"}
+    j2 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29547", "bench.py", "--gpus", "2", "--steps", "3", "--dump-records", r2] + SMALL, test_env)
+    # no launcher: bench.py spawns its own two ranks
+    j3 = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--dump-records", r3] + SMALL, test_env)
+    a, b, c = np.load(r1), np.load(r2), np.load(r3)
+    assert a.shape == b.shape == c.shape == (6, 24) and a.dtype == np.float64
+    keep = [i for i in range(24) if i != 22]                      # column 22 = model_ms (a measurement)
+    assert np.array_equal(a[:, keep], b[:, keep]) and np.array_equal(a[:, keep], c[:, keep])
+    assert list(a[:, 0]) == [0, 1, 2, 3, 4, 5]
+    for j, n in ((j1, 1), (j2, 2), (j3, 2)):
+        assert j["n_gpus"] == n and j["unit"] == "pairs/s" and j["value"] > 0 and j["scaling"] == "weak"
+        assert j["roofline"]["bound"] == "mfma" and j["roofline_neighbour_gather"]["bound"] == "hbm"
+        assert set(j["work"]) >= {"mean_m_per_scale", "mean_M", "mean_C", "mean_ransac_iters"}
+    assert j1["registered_ok"] == j2["registered_ok"] == j3["registered_ok"]

@@ -1,0 +1,307 @@
+"""GPU parity at the HEADLINE configuration (BASELINE configs[1]: K = 5000 keypoints, P = 1024 points per patch, 3 scales) and
+at configs[0] (1 scale, 512 keypoints, 512 points per patch).
+
+The CPU oracle cannot run a whole K = 5000 pair inside a test, so bx_register_pair runs with bx_set_capture armed and every
+stage is checked on a random sample of its units against the oracle stage FED THE GPU'S OWN UPSTREAM TENSORS -- a stage whose
+output differed from the oracle's on the same input would be caught wherever in the chain it sits.  Cheap stages (mutual
+matching at 5000 x 5000, hypotheses, consensus at M ~ 4000..15000, RANSAC, refinement) are checked in full.  All comparisons are
+bit-exact (the arithmetic contract of oracle/bx_oracle.c).  Reference: models/BUFFERX.py:257-467, models/patch_embedder.py:44-170,
+models/patchnet.py:49-84,184-210, models/pose_estimator.py:84-117."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+K, P, S = 5000, 1024, 3
+NSAMP = 64
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _headline_cfg(bx):
+    cfg = bx.make_cfg("3DMatch")
+    cfg.patch.num_fps, cfg.patch.num_points_per_patch, cfg.patch.num_scales = K, P, S
+    cfg.patch.search_radius_thresholds = [5, 2, 0.5]
+    return cfg
+
+
+@pytest.fixture(scope="module")
+def headline(bx, packed, oracle):
+    """One K = 5000 / P = 1024 / S = 3 pair (noise-free partial overlap, 45k-point fragments) run three times with the capture
+    armed on (scale 0, src), (scale 1, tgt), (scale 2, src): the result must not depend on the capture."""
+    import torch
+    from bufferx_amd import lib
+    cfg = _headline_cfg(bx)
+    pair = bx.synth.make_pair(77, "indoor", n_target=45000, shared=True)
+    seed = 5
+    ctx = lib.Context(cfg, max_points=max(len(pair["src"]), len(pair["tgt"])), device=0, packed_weights=packed)
+    rng = np.random.default_rng(seed)
+    perm = [np.stack([rng.permutation(len(pair[k])).astype(np.int32) for _ in range(S)]) for k in ("src", "tgt")]
+    runs = []
+    for scale, cloud in ((0, 0), (1, 1), (2, 0)):
+        n = len(pair["src" if cloud == 0 else "tgt"])
+        cap = ctx.set_capture(scale, cloud, n)
+        res = ctx.register_pair(pair["src"], pair["tgt"], pair["aligned_z"], perm[0], perm[1], seed)
+        torch.cuda.synchronize()
+        out = dict(scale=scale, cloud=cloud, cap=cap, pose=np.array(res.pose).reshape(4, 4),
+                   tup=(res.num_inliers, res.num_mutual, res.num_inlier_ind, res.scales_used, res.ransac_iters, res.refine_iters),
+                   des_r=[float(res.des_r[i]) for i in range(S)], status=res.status)
+        runs.append(out)
+    ctx.set_capture(None, 0, 0)
+    plain = ctx.register_pair(pair["src"], pair["tgt"], pair["aligned_z"], perm[0], perm[1], seed)
+    plain = (np.array(plain.pose).reshape(4, 4), (plain.num_inliers, plain.num_mutual, plain.num_inlier_ind, plain.scales_used,
+                                                   plain.ransac_iters, plain.refine_iters))
+    yield dict(cfg=cfg, pair=pair, perm=perm, seed=seed, runs=runs, plain=plain, ctx=ctx)
+    ctx.close()
+
+
+def test_headline_runs_agree(headline):
+    """capture on / off and the three captured runs give the identical result; all three scales ran."""
+    p0, t0 = headline["plain"]
+    for r in headline["runs"]:
+        assert r["status"] == 0
+        assert np.array_equal(r["pose"], p0) and r["tup"] == t0
+    assert t0[3] == S and t0[1] > 0
+
+
+@pytest.mark.parametrize("ri", [0, 1, 2])
+def test_headline_descriptor_chain(headline, oracle, packed, bx, ri):
+    """permute -> select_patches -> axis_align / SPT / pnt_layer -> Cylindrical_Net (8 layers) -> pool_layer + norms on NSAMP random
+    keypoints of the captured (scale, cloud), each stage fed the GPU tensor of the stage before it."""
+    import torch
+    from bufferx_amd import lib
+    W = bx.weights
+    run, cfg, pair = headline["runs"][ri], headline["cfg"], headline["pair"]
+    cap, scale, cloud = run["cap"], run["scale"], run["cloud"]
+    cloud_pts = pair["src" if cloud == 0 else "tgt"]
+    pts_perm = _np(cap["pts_perm"])
+    assert np.array_equal(pts_perm, cloud_pts[headline["perm"][cloud][scale]])
+    kpts = _np(cap["kpts"][cloud])
+    assert np.array_equal(kpts, cloud_pts[oracle.fps(cloud_pts, K)])                       # FPS at K = 5000, in full
+    des_r = run["des_r"][scale]
+    rng = np.random.default_rng(100 + ri)
+    sel = np.sort(rng.choice(K, NSAMP, replace=False))
+    tsel = torch.as_tensor(sel, device=cap["patches"].device)
+    # select_patches
+    g_patches = _np(cap["patches"][tsel])
+    _, o_patches = oracle.ball_group(pts_perm, kpts[sel], np.float32(des_r), P)
+    assert np.array_equal(g_patches, o_patches)
+    # patch features
+    o_R, o_feat = oracle.patch_features(g_patches, des_r, pair["aligned_z"], packed["pnt_w"], packed["pnt_b"])
+    assert np.array_equal(_np(cap["R"][cloud][tsel]), o_R.reshape(-1, 9))
+    g_feat = lib.chunked_to_logical(_np(cap["feat"][tsel]))         # the oracle keeps logical channel order
+    assert np.array_equal(g_feat, o_feat)
+    # conv stack (the per-layer check at persistent-walk sizes is test_conv_layers_group_walk)
+    tap = W.cyl_tap_table(cfg.patch.ele_n, cfg.patch.azi_n)
+    x = g_feat
+    for L in packed["desc"]:
+        x = oracle.conv(x, tap, L["W"], L["b"], L["relu"])
+    g_x = lib.chunked_to_logical(_np(cap["x"][tsel]))
+    assert np.array_equal(g_x, x)
+    # head
+    o_desc, o_equi = oracle.desc_head(g_x, packed["pool_w1"], packed["pool_b1"], packed["pool_w2"], packed["pool_b2"])
+    assert np.array_equal(_np(cap["desc"][cloud][tsel]), o_desc)
+    assert np.array_equal(_np(cap["equi"][cloud][tsel]), o_equi)
+
+
+@pytest.mark.parametrize("ri", [0, 1, 2])
+def test_headline_matching_chain(headline, oracle, packed, bx, ri):
+    """mutual matching over all 5000 x 5000 descriptors, CostVolume + CostNet + soft-argmax on NSAMP random matches, hypotheses and
+    the cumulative consensus (every hypothesis, every correspondence) of the captured scale."""
+    import torch
+    from oracle import pipeline as PL
+    run, cfg = headline["runs"][ri], headline["cfg"]
+    cap, scale = run["cap"], run["scale"]
+    m, M, C, best = [int(v) for v in _np(cap["counts"])]
+    d0, d1 = _np(cap["desc"][0]), _np(cap["desc"][1])
+    o_s, o_t, _, _ = oracle.mutual(d0, d1)
+    assert m == len(o_s) and m > 64
+    s_mids, t_mids = _np(cap["s_mids"])[:m], _np(cap["t_mids"])[:m]
+    assert np.array_equal(s_mids, o_s) and np.array_equal(t_mids, o_t)
+    # CostNet on a sample of the matches: gather the two equivariant maps of the sampled matches on the device
+    rng = np.random.default_rng(200 + ri)
+    sel = np.sort(rng.choice(m, NSAMP, replace=False))
+    dev = cap["equi"][0].device
+    e0 = _np(cap["equi"][0][torch.as_tensor(s_mids[sel].astype(np.int64), device=dev)])
+    e1 = _np(cap["equi"][1][torch.as_tensor(t_mids[sel].astype(np.int64), device=dev)])
+    ar = np.arange(NSAMP, dtype=np.int32)
+    o_ind = PL.pose_forward(e0, e1, ar, ar, packed, cfg)
+    g_ind = _np(cap["ind"])[:m]
+    assert np.array_equal(g_ind[sel], o_ind)
+    # hypotheses of this scale = the last m rows of the accumulated tensors
+    R0, R1 = _np(cap["R"][0]), _np(cap["R"][1])
+    k0, k1 = _np(cap["kpts"][0]), _np(cap["kpts"][1])
+    o_R, o_tr = oracle.hypotheses(g_ind, R0[s_mids], R1[t_mids], k0[s_mids], k1[t_mids], cfg.patch.azi_n)
+    R_cat, t_cat = _np(cap["R_cat"])[:M], _np(cap["t_cat"])[:M]
+    ss, tt = _np(cap["ss_cat"])[:M], _np(cap["tt_cat"])[:M]
+    assert np.array_equal(R_cat[M - m:], o_R) and np.array_equal(t_cat[M - m:], o_tr)
+    assert np.array_equal(ss[M - m:], k0[s_mids]) and np.array_equal(tt[M - m:], k1[t_mids])
+    # consensus over everything accumulated so far
+    o_inl, o_best, o_counts = oracle.consensus(R_cat, t_cat, ss, tt, cfg.match.inlier_th, cfg.patch.azi_n)
+    assert best == o_best and C == len(o_inl)
+    assert np.array_equal(_np(cap["cons_cnt"])[:M], o_counts)
+    assert np.array_equal(_np(cap["inlier_ind"])[:C], o_inl)
+    if scale == S - 1:
+        assert M == run["tup"][1] and C == run["tup"][2]
+
+
+def test_headline_pose(headline, oracle):
+    """RANSAC (fp64, seeded) and post_refinement from the captured correspondences of the last scale == the returned pose."""
+    run, cfg, seed = headline["runs"][2], headline["cfg"], headline["seed"]
+    cap = run["cap"]
+    m, M, C, best = [int(v) for v in _np(cap["counts"])]
+    ss, tt = _np(cap["ss_cat"])[:M], _np(cap["tt_cat"])[:M]
+    inl = _np(cap["inlier_ind"])[:C]
+    T, n, it = oracle.ransac(ss, tt, inl, cfg.match.dist_th, cfg.match.similar_th, cfg.match.confidence, cfg.match.iter_n,
+                             oracle.mix64(seed, 0x5AC0000))
+    assert np.array_equal(_np(cap["T_ransac"]).reshape(4, 4), T)
+    assert (n, it) == (run["tup"][0], run["tup"][4])
+    Tr, rit = oracle.refine(ss, tt, cfg.match.dist_th, T.astype(np.float32))
+    assert np.array_equal(run["pose"], Tr.reshape(4, 4).astype(np.float64)) and rit == run["tup"][5]
+
+
+def test_headline_pair_registers(headline, bx):
+    """the noise-free partial-overlap pair is actually registered (RTE < 0.3 m, RRE < 15 deg: config/indoor_config.py:36-37)"""
+    cfg = headline["cfg"]
+    rre, rte = bx.synth.pose_error(headline["plain"][0], headline["pair"]["T_gt"])
+    assert rre < cfg.test.rre_thresh and rte < cfg.test.rte_thresh, (rre, rte, headline["plain"][1])
+
+
+# ------------------------------------------------------------------ every conv layer beyond the persistent-walk threshold
+DESC_SHAPES = [(3, 64), (4, 64), (4, 128), (8, 128), (8, 64), (4, 64), (4, 32), (2, 32)]
+
+
+def test_conv_layers_group_walk(bx, packed, oracle, monkeypatch):
+    """All 8 Cylindrical_Net layers at 5000 units and all 9 explicit CostNet layers at 1400 units, each run on the GPU output of
+    the layer before it, with the persistent grid capped at 48 workgroups (BX_CONV_PERSIST_CAP) so that EVERY layer walks >= 2
+    unit groups per workgroup (grp_next slab hand-off, k_conv.hip) -- plus the uncapped Desc layers, which walk at K = 5000 with
+    the real occupancy.  NSAMP random units per layer vs the oracle fed the GPU's input of that layer."""
+    import torch
+    from bufferx_amd import lib
+    W = bx.weights
+    cfg = _headline_cfg(bx)
+    rng = np.random.default_rng(3)
+    for cap_env in ("48", None):
+        if cap_env:
+            monkeypatch.setenv("BX_CONV_PERSIST_CAP", cap_env)
+        else:
+            monkeypatch.delenv("BX_CONV_PERSIST_CAP", raising=False)
+        ctx = lib.Context(cfg, max_points=4096, device=0, packed_weights=packed)
+        try:
+            # Desc: layer inputs are non-negative (post-ReLU) activations like the real ones
+            units = K
+            x = torch.as_tensor(np.abs(rng.standard_normal((units, 3, 140, 16))).astype(np.float32), device="cuda:0")
+            tap = W.cyl_tap_table(cfg.patch.ele_n, cfg.patch.azi_n)
+            for l, (L, (nch, cout)) in enumerate(zip(packed["desc"], DESC_SHAPES)):
+                assert x.shape[1] == nch
+                y = ctx.conv_layer(0, l, x, (units, (cout + 15) // 16, 140, 16))
+                sel = np.sort(rng.choice(units, NSAMP, replace=False))
+                sel[-1] = units - 1                                   # the ragged tail group
+                ts = torch.as_tensor(sel, device=x.device)
+                ref = oracle.conv(lib.chunked_to_logical(_np(x[ts])), tap, L["W"], L["b"], L["relu"])
+                assert np.array_equal(lib.chunked_to_logical(_np(y[ts])), ref), ("desc", l, cap_env)
+                x = y
+            if cap_env is None:
+                continue
+            # Pose: layer 0 consumes the implicit cost volume (bx_pose_net); layers 1..9 through bx_conv_layer
+            units = 1400
+            geo = W.pose_geometry(cfg.patch.ele_n, cfg.patch.azi_n)
+            dims0 = geo[1][0]
+            pin = int(np.prod(dims0))
+            x = torch.as_tensor(np.abs(rng.standard_normal((units, 2, pin, 16))).astype(np.float32), device="cuda:0")
+            for l in range(1, 10):
+                L = packed["pose"][l]
+                dims, k, out = geo[l]
+                tap, _ = W.valid_tap_table(dims, k)
+                cout = L["W"].shape[-1]
+                y = ctx.conv_layer(1, l, x, (units, (cout + 15) // 16, int(np.prod(out)), 16))
+                sel = np.sort(rng.choice(units, NSAMP, replace=False))
+                sel[-1] = units - 1
+                ts = torch.as_tensor(sel, device=x.device)
+                ref = oracle.conv(lib.chunked_to_logical(_np(x[ts])), tap, L["W"], L["b"], L["relu"])
+                assert np.array_equal(lib.chunked_to_logical(_np(y[ts])), ref), ("pose", l)
+                x = y
+        finally:
+            ctx.close()
+
+
+# ------------------------------------------------------------------ BASELINE configs[0]: one whole pair against the oracle
+def test_config0_pair_bit_exact(bx, packed, oracle):
+    """Single 3DMatch-like pair, 1 scale, 512 FPS keypoints, 512 points per patch, N ~ 30k, RANSAC + refinement: the whole
+    pipeline bit-identical to the CPU oracle pipeline (BASELINE.json configs[0] is exactly this CPU run)."""
+    from oracle import pipeline as PL
+    from bufferx_amd import lib
+    cfg = bx.make_cfg("3DMatch")
+    cfg.patch.num_fps, cfg.patch.num_points_per_patch, cfg.patch.num_scales = 512, 512, 1
+    cfg.patch.search_radius_thresholds = [5]
+    pair = bx.synth.make_pair(0, "indoor", n_target=30000, shared=True)
+    seed = 0
+    ctx = lib.Context(cfg, max_points=max(len(pair["src"]), len(pair["tgt"])), device=0, packed_weights=packed)
+    perm_s = np.stack([oracle.make_perm(len(pair["src"]), seed, 0)])
+    perm_t = np.stack([oracle.make_perm(len(pair["tgt"]), seed, 1)])
+    res = ctx.register_pair(pair["src"], pair["tgt"], pair["aligned_z"], perm_s, perm_t, seed)
+    ref = PL.register_pair(pair["src"], pair["tgt"], packed, cfg, pair["aligned_z"], seed)
+    ctx.close()
+    assert (res.num_inliers, res.num_mutual, res.num_inlier_ind, res.scales_used) == tuple(ref[1:])
+    assert np.array_equal(np.array(res.pose).reshape(4, 4), np.asarray(ref[0], np.float64))
+
+
+# ------------------------------------------------------------------ > 200 000 points: the radius estimation's subsample
+def test_cloud_above_200k_points(bx, packed, oracle):
+    """models/BUFFERX.py:661-665: a cloud of more than 200 000 points is subsampled (with replacement) to 200 000 for the radius
+    estimation while `num_pts` keeps the original size.  230k / 150k-point clouds, bit-exact against the oracle pipeline."""
+    from oracle import pipeline as PL
+    from bufferx_amd import lib
+    cfg = bx.make_cfg("KITTI")
+    cfg.patch.num_fps, cfg.patch.num_points_per_patch, cfg.patch.num_scales = 96, 64, 2
+    cfg.patch.search_radius_thresholds = [2, 0.5]
+    cfg.patch.num_points_radius_estimate = 128
+    cfg.match.iter_n = 800
+    rng = np.random.default_rng(12)
+    base = bx.synth.make_pair(9, "outdoor", voxel=0.05)
+    # densify the sweep: jittered copies of the surface samples
+    def dense(c, n):
+        reps = int(np.ceil(n / len(c)))
+        out = np.concatenate([c + rng.normal(0, 0.02, c.shape).astype(np.float32) for _ in range(reps)])[:n]
+        return np.ascontiguousarray(out[rng.permutation(n)], np.float32)
+    src, tgt = dense(base["src"], 230000), dense(base["tgt"], 150000)
+    seed = 3
+    ctx = lib.Context(cfg, max_points=len(src), device=0, packed_weights=packed)
+    S2 = 2
+    perm_s = np.stack([oracle.make_perm(len(src), seed, 2 * i) for i in range(S2)])
+    perm_t = np.stack([oracle.make_perm(len(tgt), seed, 2 * i + 1) for i in range(S2)])
+    res = ctx.register_pair(src, tgt, True, perm_s, perm_t, seed)
+    ref = PL.register_pair(src, tgt, packed, cfg, True, seed)
+    ctx.close()
+    assert (res.num_inliers, res.num_mutual, res.num_inlier_ind, res.scales_used) == tuple(ref[1:])
+    assert np.array_equal(np.array(res.pose).reshape(4, 4), np.asarray(ref[0], np.float64))
+
+
+# ------------------------------------------------------------------ early exit armed but NOT taken, 3 scales
+def test_early_exit_not_taken_three_scales(bx, packed, oracle):
+    """enable_early_exit with a threshold the first scale cannot reach (models/BUFFERX.py:424-457): the RANSAC call of scale 0 runs,
+    the exit is not taken, all three scales run and a second RANSAC call (next seed stream) produces the pose."""
+    from oracle import pipeline as PL
+    from bufferx_amd import lib
+    cfg = bx.make_cfg("3DMatch")
+    cfg.patch.num_fps, cfg.patch.num_points_per_patch, cfg.patch.num_scales = 200, 96, 3
+    cfg.patch.search_radius_thresholds = [5, 2, 0.5]
+    cfg.patch.num_points_radius_estimate = 200
+    cfg.match.iter_n = 3000
+    cfg.match.enable_early_exit = True
+    cfg.match.early_exit_min_inliers = 100000
+    pair = bx.synth.make_pair(14, "indoor", n_target=6000, identical=True)
+    seed = 21
+    ctx = lib.Context(cfg, max_points=len(pair["src"]), device=0, packed_weights=packed)
+    perm_s = np.stack([oracle.make_perm(len(pair["src"]), seed, 2 * i) for i in range(3)])
+    perm_t = np.stack([oracle.make_perm(len(pair["tgt"]), seed, 2 * i + 1) for i in range(3)])
+    res = ctx.register_pair(pair["src"], pair["tgt"], pair["aligned_z"], perm_s, perm_t, seed)
+    ref = PL.register_pair(pair["src"], pair["tgt"], packed, cfg, pair["aligned_z"], seed)
+    ctx.close()
+    assert res.scales_used == 3 and ref[4] == 3
+    assert (res.num_inliers, res.num_mutual, res.num_inlier_ind, res.scales_used) == tuple(ref[1:])
+    assert np.array_equal(np.array(res.pose).reshape(4, 4), np.asarray(ref[0], np.float64))
