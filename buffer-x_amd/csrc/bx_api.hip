@@ -127,6 +127,7 @@ void carve(bx_ctx* c, char* base, size_t* total)
     c->state = cv.take<PairState>(1);
     c->result_dev = cv.take<bx_result>(1);
     c->err_flag = cv.take<int32_t>(4);
+    c->conv_ctr = cv.take<int32_t>(2 * BX_NDESC);
     *total = (cv.off + 255) & ~(size_t)255;
 }
 
@@ -330,6 +331,10 @@ static int create_impl(bx_ctx* c, int device_id)
         c->conv_persist = (!e || atoi(e) != 0) ? 1 : 0;
         e = getenv("BX_CONV_PERSIST_CAP");
         c->conv_cap_override = e ? atoi(e) : 0;
+        e = getenv("BX_CONV32");        // 0: Cylindrical_Net on the 16x16x4 kernels of k_conv.hip (A/B measurements)
+        c->use_conv32 = (!e || atoi(e) != 0) ? 1 : 0;
+        e = getenv("BX_CONV_STAGGER");  // experiment: start delay for every second block of this many workgroups (0 = off)
+        c->conv_stagger = e ? atoi(e) : 0;
     }
     (void)p;
     c->prof = new std::vector<ProfEvt>();
@@ -345,6 +350,7 @@ static int create_impl(bx_ctx* c, int device_id)
     carve(c, c->arena, &total);
     BX_HIP(hipMemset(c->state, 0, sizeof(PairState)));
     BX_HIP(hipMemset(c->err_flag, 0, 4 * sizeof(int32_t)));
+    BX_HIP(hipMemset(c->conv_ctr, 0, 2 * BX_NDESC * sizeof(int32_t)));
     std::vector<float> cen, rot, rowc;
     voxel_tables(cen, rot, rowc);
     int rc;
@@ -410,7 +416,7 @@ int bx_destroy(bx_ctx* c)
     (void)hipFree(c->arena);
     (void)hipFree(c->d_centres); (void)hipFree(c->d_rot); (void)hipFree(c->d_rowc); (void)hipFree(c->d_rad_thr);
     (void)hipFree(c->d_pnt_w); (void)hipFree(c->d_pnt_b); (void)hipFree(c->d_pool_w1); (void)hipFree(c->d_pool_b1); (void)hipFree(c->d_pool_w2); (void)hipFree(c->d_pool_b2);
-    for (int i = 0; i < BX_NDESC; ++i) { (void)hipFree(c->desc[i].W); (void)hipFree(c->desc[i].b); (void)hipFree(c->desc[i].lrow); (void)hipFree(c->desc[i].lrow2); (void)hipFree(c->desc[i].obase); (void)hipFree(c->desc[i].toff); }
+    for (int i = 0; i < BX_NDESC; ++i) { (void)hipFree(c->desc[i].W); (void)hipFree(c->desc[i].W32); (void)hipFree(c->desc[i].b); (void)hipFree(c->desc[i].lrow); (void)hipFree(c->desc[i].lrow2); (void)hipFree(c->desc[i].obase); (void)hipFree(c->desc[i].toff); }
     for (int i = 0; i < BX_NPOSE; ++i) { (void)hipFree(c->pose[i].W); (void)hipFree(c->pose[i].b); (void)hipFree(c->pose[i].lrow); (void)hipFree(c->pose[i].lrow2); (void)hipFree(c->pose[i].obase); (void)hipFree(c->pose[i].toff); }
     delete c;
     return BX_OK;
@@ -489,6 +495,17 @@ int bx_load_weights(bx_ctx* c, const bx_weights* w)
                         }
         return upload(&L.W, wp.data(), wp.size());
     };
+    // 32x32x2 form: element j of lane (kk = lane >> 5, n = lane & 31) = W[chunk][tap][2 j + kk][tile*32 + n]
+    auto upload_w32 = [&](ConvLayerDev& L, const float* wsrc) -> int {
+        const int nct = L.nchunk * L.ntaps, nt = L.cout / 32;
+        std::vector<float> wp((size_t)nct * nt * 64 * 8, 0.0f);
+        for (int ct = 0; ct < nct; ++ct)
+            for (int t = 0; t < nt; ++t)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j)
+                        wp[(((size_t)ct * nt + t) * 64 + lane) * 8 + j] = wsrc[((size_t)ct * 16 + 2 * j + (lane >> 5)) * L.cout + t * 32 + (lane & 31)];
+        return upload(&L.W32, wp.data(), wp.size());
+    };
     const ConvGeo cg = cyl_geo();
     auto upload_geo = [&](ConvLayerDev& L, const ConvGeo& g) -> int {
         int r;
@@ -502,6 +519,7 @@ int bx_load_weights(bx_ctx* c, const bx_weights* w)
         ConvLayerDev& L = c->desc[l];
         L.nchunk = dc[l][0]; L.ntaps = 9; L.p_in = BX_EA; L.p_out = BX_EA; L.cout = dc[l][1]; L.relu = l < BX_NDESC - 1;
         if ((rc = upload_w(L, w->desc_w[l])) != BX_OK) return rc;
+        if ((rc = upload_w32(L, w->desc_w[l])) != BX_OK) return rc;
         if ((rc = upload(&L.b, w->desc_b[l], (size_t)L.cout)) != BX_OK) return rc;
         if ((rc = upload_geo(L, cg)) != BX_OK) return rc;
     }

@@ -42,7 +42,8 @@ constexpr int BX_VOX = BX_RAD * BX_EA;          // 420 voxels
 constexpr int BX_NDESC = 8, BX_NPOSE = 10;
 
 struct ConvLayerDev {
-    float* W;        // [nchunk][ntaps][16][cout]
+    float* W;        // B fragments of the 16x16x4 kernels: [chunk*taps][column tile 16][lane][4]
+    float* W32;      // B fragments of the 32x32x2 kernels (k_conv32.hip): [chunk*taps][column tile 32][lane][8]; Desc layers only
     float* b;        // [cout]
     int32_t* lrow;   // [p_in]  LDS row of an input position inside a unit's p_lds-row slab
     int32_t* lrow2;  // [p_in]  second copy (azimuth wrap halo) or -1
@@ -159,7 +160,9 @@ struct bx_ctx {
     struct bx_lane* lane;               // optional: orders the MFMA-heavy sections of the pairs of several contexts (bx_attach_lane)
     void* pre;                          // bx_pre_ws* (k_pre.hip): workspace of the pre-processing entry points, reserved on demand
     int conv_cap[2][BX_NPOSE];          // persistent-grid size of every conv layer on THIS device (0 = not set up yet)
-    int conv_persist, conv_cap_override, n_cu;
+    int conv32_cap[BX_NDESC];           // the same for the 32x32x2 kernels (k_conv32.hip)
+    int conv_persist, conv_cap_override, n_cu, use_conv32, conv_stagger;
+    int32_t* conv_ctr;                  // [2 * BX_NDESC] {next group ticket, departed workgroups} of the 32x32x2 kernels' group walk
     bx_capture cap;                     // bx_set_capture: intermediates of one scale copied to caller buffers
     int cap_on;
     int prof_on;
@@ -180,6 +183,7 @@ int bxk_patch_features(bx_ctx* c, hipStream_t s, const float* patches, int K, in
                        float* R_out, float* feat_out);
 int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, const int32_t* units_dev, int max_units,
              float* out);
+int bxk_conv32(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t* units_dev, int max_units, float* out);
 int bxk_cost_l1(bx_ctx* c, hipStream_t s, const float* s_equi, const float* t_equi, const int32_t* s_mids,
                 const int32_t* t_mids, const int32_t* m_dev, int max_m, float* out);
 int bxk_desc_head(bx_ctx* c, hipStream_t s, const float* x, int K, float* desc, float* equi);
