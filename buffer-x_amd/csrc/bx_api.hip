@@ -331,10 +331,11 @@ static int create_impl(bx_ctx* c, int device_id)
         c->conv_persist = (!e || atoi(e) != 0) ? 1 : 0;
         e = getenv("BX_CONV_PERSIST_CAP");
         c->conv_cap_override = e ? atoi(e) : 0;
-        e = getenv("BX_CONV32");        // 0: Cylindrical_Net on the 16x16x4 kernels of k_conv.hip (A/B measurements)
-        c->use_conv32 = (!e || atoi(e) != 0) ? 1 : 0;
-        e = getenv("BX_CONV_STAGGER");  // experiment: start delay for every second block of this many workgroups (0 = off)
-        c->conv_stagger = e ? atoi(e) : 0;
+        // BX_CONV32=1: Cylindrical_Net layers 0-5 on the 32x32x2 loader/compute kernels of k_conv32.hip instead of the 16x16x4
+        // kernels of k_conv.hip.  Bit-identical results; measured layer by layer within +-2 % of each other (both sit
+        // at ~90 % matrix-pipe occupancy and the chip lowers its clock as the occupancy rises), the 16x16x4 form is the default.
+        e = getenv("BX_CONV32");
+        c->use_conv32 = (e && atoi(e) != 0) ? 1 : 0;
     }
     (void)p;
     c->prof = new std::vector<ProfEvt>();

@@ -161,7 +161,7 @@ struct bx_ctx {
     void* pre;                          // bx_pre_ws* (k_pre.hip): workspace of the pre-processing entry points, reserved on demand
     int conv_cap[2][BX_NPOSE];          // persistent-grid size of every conv layer on THIS device (0 = not set up yet)
     int conv32_cap[BX_NDESC];           // the same for the 32x32x2 kernels (k_conv32.hip)
-    int conv_persist, conv_cap_override, n_cu, use_conv32, conv_stagger;
+    int conv_persist, conv_cap_override, n_cu, use_conv32;
     int32_t* conv_ctr;                  // [2 * BX_NDESC] {next group ticket, departed workgroups} of the 32x32x2 kernels' group walk
     bx_capture cap;                     // bx_set_capture: intermediates of one scale copied to caller buffers
     int cap_on;
