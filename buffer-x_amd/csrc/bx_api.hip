@@ -82,7 +82,6 @@ void carve(bx_ctx* c, char* base, size_t* total)
     c->act0 = cv.take<float>(act);
     c->act1 = cv.take<float>(act);
     c->patches = cv.take<float>(K * P * 3);
-    c->ball_idx = cv.take<int32_t>(K * P);
     c->feat = cv.take<float>(K * BX_RAD * BX_EA * 16);
     c->pts_perm = cv.take<float>(NMAX * 3);
     for (int i = 0; i < 2; ++i) {
@@ -113,16 +112,22 @@ void carve(bx_ctx* c, char* base, size_t* total)
     c->refine_ws = cv.take<float>(SK * 2);
     c->refine_sel = cv.take<int32_t>(SK);
     c->sub_pts = cv.take<float>(NMAX > 200000 ? (size_t)200000 * 3 : 16);
-    c->ball_bbox = cv.take<int32_t>(8);
-    c->ball_grid = cv.take<BallGrid>(1);
-    c->ball_cnt = cv.take<int32_t>((size_t)BX_BALL_NCELL + 2 * 2048);
-    c->ball_start = cv.take<int32_t>((size_t)BX_BALL_NCELL + 2 * 2048);
-    c->ball_bsum = cv.take<int32_t>(BX_BALL_NCELL / 2048 + 2);
-    c->ball_cellrank = cv.take<int2>(NMAX);
-    c->ball_rowtab = cv.take<int2>(KM * 64);
-    c->ball_chunktab = cv.take<int4>(KM * 64);
-    c->ball_pts4 = cv.take<float4>(NMAX);
-    c->ball_sorted = cv.take<float4>(NMAX);
+    const size_t NS = 2 * S;                      // grid sets: (cloud, scale)
+    c->ball_nsets = (int)NS;
+    c->ball_st_cnt = (size_t)BX_BALL_NCELL + 2 * 2048;
+    c->ball_st_bsum = BX_BALL_NCELL / 2048 + 2;
+    c->ball_st_pts = (NMAX + 63) & ~(size_t)63;
+    c->ball_st_tab = KM * 64;
+    c->ball_bbox_part = cv.take<float>(2 * 64 * 6);
+    c->ball_grid = cv.take<BallGrid>(NS);
+    c->ball_cnt = cv.take<int32_t>(NS * c->ball_st_cnt);
+    c->ball_start = cv.take<int32_t>(NS * c->ball_st_cnt);
+    c->ball_bsum = cv.take<int32_t>(NS * c->ball_st_bsum);
+    c->ball_cellrank = cv.take<int2>(NS * c->ball_st_pts);
+    c->ball_rowtab = cv.take<int2>(NS * c->ball_st_tab);
+    c->ball_chunktab = cv.take<int4>(NS * c->ball_st_tab);
+    c->ball_pts4 = cv.take<float4>(NS * c->ball_st_pts);
+    c->ball_sorted = cv.take<float4>(NS * c->ball_st_pts);
     c->ball_dbg = cv.take<long long>(64 * 8);
     c->state = cv.take<PairState>(1);
     c->result_dev = cv.take<bx_result>(1);
@@ -352,6 +357,7 @@ static int create_impl(bx_ctx* c, int device_id)
     BX_HIP(hipMemset(c->state, 0, sizeof(PairState)));
     BX_HIP(hipMemset(c->err_flag, 0, 4 * sizeof(int32_t)));
     BX_HIP(hipMemset(c->conv_ctr, 0, 2 * BX_NDESC * sizeof(int32_t)));
+    BX_HIP(hipMemset(c->ball_cnt, 0, (size_t)c->ball_nsets * c->ball_st_cnt * sizeof(int32_t)));   // kept zero by scan_apply_kernel
     std::vector<float> cen, rot, rowc;
     voxel_tables(cen, rot, rowc);
     int rc;
@@ -562,9 +568,7 @@ int bx_radius(bx_ctx* c, void* stream, const float* pts, int32_t n_pts, int64_t 
     BX_ENTER(c, false);
     if (!pts || !kpts || !thresholds_host || !des_r_out || n_pts < 1 || nk < 1) { bx_set_error("bx_radius: bad argument"); return BX_ERR_ARG; }
     if ((rc = bxk_radius_hist(c, (hipStream_t)stream, pts, n_pts, kpts, nk)) != BX_OK) return rc;
-    for (int i = 0; i < nthr; ++i)
-        if ((rc = bxk_radius_bisect(c, (hipStream_t)stream, n_orig, nk, thresholds_host[i], des_r_out + i)) != BX_OK) return rc;
-    return BX_OK;
+    return bxk_radius_bisect_all(c, (hipStream_t)stream, n_orig, nk, thresholds_host, nthr, des_r_out);
 }
 
 int bx_permute(bx_ctx* c, void* stream, const float* pts, const int32_t* perm, int32_t n, float* out)
@@ -769,19 +773,25 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
     }
     { ProfScope ps(c, s, 1); if ((rc = bxk_radius_hist(c, s, rpts, rn, c->kpts[big], NK)) != BX_OK) return rc; }
 
+    // every scale's radius up front (the bisections share the histogram: one launch), then the grids + candidate row tables of
+    // all 2 x S (cloud, scale) sets in one batch of six launches; the per-scale permutation is applied on the fly
+    { ProfScope ps(c, s, 1); if ((rc = bxk_radius_bisect_all(c, s, (int64_t)ns[big], NK, p.search_radius_thresholds, S, st->des_r)) != BX_OK) return rc; }
+    { ProfScope ps(c, s, 13); if ((rc = bxk_ball_prepare(c, s, clouds, ns, perms, c->kpts, 2, K, st->des_r, S)) != BX_OK) return rc; }
+
     const bool early = p.enable_early_exit != 0;
     int ransac_calls = 0;
     for (int i = 0; i < S; ++i) {
         c->skip = (early && i > 0) ? &st->done : nullptr;
-        { ProfScope ps(c, s, 1); if ((rc = bxk_radius_bisect(c, s, (int64_t)ns[big], NK, p.search_radius_thresholds[i], &st->des_r[i])) != BX_OK) return rc; }
         const bool capi = c->cap_on && c->cap.scale == i;
         for (int cl = 0; cl < 2; ++cl) {
             const bool capc = capi && c->cap.cloud == cl;
-            { ProfScope ps(c, s, 11); if ((rc = bx_permute_launch(s, clouds[cl], perms[cl] + (size_t)i * ns[cl], ns[cl], c->pts_perm, c->skip)) != BX_OK) return rc; }
             // expected neighbourhood = threshold % of the cloud: large ones get 4 waves per keypoint, small ones 2 (measured)
             c->ball_waves_hint = p.search_radius_thresholds[i] >= 1.5 ? 4 : 2;
             // the whole-pair path does not need the ball_query index list (nothing downstream reads it): idx_out = nullptr
-            { ProfScope ps(c, s, 2); if ((rc = bxk_ball_group(c, s, c->pts_perm, ns[cl], c->kpts[cl], K, &st->des_r[i], P, nullptr, c->patches)) != BX_OK) return rc; }
+            { ProfScope ps(c, s, 2); if ((rc = bxk_ball_query(c, s, cl * S + i, ns[cl], c->kpts[cl], K, &st->des_r[i], P, nullptr, c->patches)) != BX_OK) return rc; }
+            if (capc && c->cap.pts_perm) {      // the permuted cloud is never materialised on the hot path
+                if ((rc = bx_permute_launch(s, clouds[cl], perms[cl] + (size_t)i * ns[cl], ns[cl], c->pts_perm, nullptr)) != BX_OK) return rc;
+            }
             { ProfScope ps(c, s, 3); if ((rc = bxk_patch_features(c, s, c->patches, K, P, &st->des_r[i], aligned_z, c->Rpatch[cl], c->feat)) != BX_OK) return rc; }
             if (capc) {
                 if ((rc = cap_copy(s, c->cap.pts_perm, c->pts_perm, (size_t)ns[cl] * 3)) != BX_OK) return rc;

@@ -142,14 +142,17 @@ struct bx_ctx {
     int32_t* refine_sel;                // [S*K]
     float* sub_pts;                     // [200000][3] subsample buffer for radius estimation
     // neighbour-gather grid (k_ball.hip)
-    int32_t* ball_bbox;                 // [8] ordered-int min/max
-    BallGrid* ball_grid;
-    int32_t *ball_cnt, *ball_start;     // [BX_BALL_NCELL + 2 tiles]
-    int32_t* ball_bsum;                 // per scan tile
-    int2* ball_cellrank;                // [max_points]
-    int2* ball_rowtab;                  // [num_fps][64] per-keypoint candidate row table (ball_rows_kernel)
-    int4* ball_chunktab;                // [num_fps][64] per-keypoint chunk table {row-boundary mask lo, hi, rows in front, 0}
-    float4 *ball_pts4, *ball_sorted;    // [max_points] {x,y,z,0} in permuted order / {x,y,z,bits(i)} sorted by cell
+    // ... one "set" per (cloud, scale) of a pair: ball_nsets = 2 * num_scales; element j of a per-set array at base + j * stride
+    int ball_nsets;
+    size_t ball_st_cnt, ball_st_bsum, ball_st_pts, ball_st_tab;
+    float* ball_bbox_part;              // [2][64][6] per-block bounds of the two clouds
+    BallGrid* ball_grid;                // [nsets]
+    int32_t *ball_cnt, *ball_start;     // [nsets][BX_BALL_NCELL + 2 tiles]; cnt is all zeros between launches
+    int32_t* ball_bsum;                 // [nsets] per scan tile
+    int2* ball_cellrank;                // [nsets][max_points]
+    int2* ball_rowtab;                  // [nsets][num_fps][64] per-keypoint candidate row table (ball_rows_kernel)
+    int4* ball_chunktab;                // [nsets][num_fps][64] per-keypoint chunk table {row-boundary mask lo, hi, rows in front, 0}
+    float4 *ball_pts4, *ball_sorted;    // [nsets][max_points] {x,y,z,0} in permuted order / {x,y,z,bits(i)} sorted by cell
     long long ball_attr_set;
     int ball_waves_hint;                // waves per keypoint of the next neighbour-gather launch (0 = default 2)
     long long* ball_dbg;                // [64][8] cycle stamps (BX_BALL_DEBUG)
@@ -179,6 +182,11 @@ int bxk_radius_hist(bx_ctx* c, hipStream_t s, const float* pts, int n_pts, const
 int bxk_radius_bisect(bx_ctx* c, hipStream_t s, int64_t n_orig, int nk, double threshold, double* des_r_out);
 int bxk_ball_group(bx_ctx* c, hipStream_t s, const float* pts_perm, int n, const float* kpts, int K, const double* radius,
                    int P, int32_t* idx_out, float* patches_out);
+int bxk_ball_prepare(bx_ctx* c, hipStream_t s, const float* const* clouds, const int* ns, const int32_t* const* perms,
+                     const float* const* kpts, int nclouds, int K, const double* radius, int S);
+int bxk_ball_query(bx_ctx* c, hipStream_t s, int set, int n, const float* kpts, int K, const double* radius, int P,
+                   int32_t* idx_out, float* patches_out);
+int bxk_radius_bisect_all(bx_ctx* c, hipStream_t s, int64_t n_orig, int nk, const double* thresholds_host, int nthr, double* des_r_out);
 int bxk_patch_features(bx_ctx* c, hipStream_t s, const float* patches, int K, int P, const double* radius, int aligned,
                        float* R_out, float* feat_out);
 int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, const int32_t* units_dev, int max_units,

@@ -25,6 +25,7 @@
 // roughly K * (points in 27 cells).
 #include "bx_common.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -49,19 +50,38 @@ __device__ __forceinline__ int f2ord(float f)
 }
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
-__global__ void bbox_init_kernel(int32_t* bbox, const int32_t* __restrict__ skip)
-{
-    if (skip && *skip) return;
-    if (threadIdx.x < 3) bbox[threadIdx.x] = 0x7fffffff;
-    else if (threadIdx.x < 6) bbox[threadIdx.x] = (int)0x80000000;
-}
+// ---------------------------------------------------------------------------------------------- batched grid build
+// One pair needs 2 clouds x S scales grids (the cell edge follows the radius of the scale).  All of them are built by ONE
+// sequence of six launches whose blockIdx.y selects the grid ("set" j = cloud * S + scale): the 9 small launches per stage call
+// of round 1 (x 6 calls per pair) had become longer than the query kernel itself.  The permutation of the cloud
+// (models/patch_embedder.py:96-97) is applied on the fly: point i of set j is pts[perm_j[i]].
+struct BallBatch {
+    const float* pts[2];        // cloud of sets [0, S) and [S, 2S)
+    const int32_t* perm[2];     // [S][n] permutations of the cloud, nullptr: identity (the stage entry point gets a permuted cloud)
+    const float* kpts[2];
+    int n[2];
+    int S, nsets, K;
+    const double* radius;       // device: radius of scale i at radius[i]
+    // per-set arrays: element j at base + j * stride
+    float* bbox_part;           // [2][64][6]
+    BallGrid* grid;
+    int32_t *cnt, *start, *bsum;
+    int2* cellrank;
+    float4 *pts4, *sorted;
+    int2* rowtab;
+    int4* chunktab;
+    size_t st_cnt, st_bsum, st_pts, st_tab;
+};
 
-// <= 64 workgroups; one device-scope atomic per workgroup and bound (same-address device atomics cost ~12 ns each)
-__global__ __launch_bounds__(1024) void bbox_kernel(const float* __restrict__ pts, int n, int32_t* bbox, const int32_t* __restrict__ skip)
+// per-block partial bounds of a cloud (64 blocks x 2 clouds, no atomics, no initialisation launch)
+__global__ __launch_bounds__(1024) void bbox_kernel(BallBatch B)
 {
-    if (skip && *skip) return;
     __shared__ float red[16][6];
+    const int cl = blockIdx.y;
+    const float* __restrict__ pts = B.pts[cl];
+    const int n = B.n[cl];
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    if (pts)
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -88,26 +108,37 @@ __global__ __launch_bounds__(1024) void bbox_kernel(const float* __restrict__ pt
         const int c = threadIdx.x;
         float v = red[0][c];
         for (int w = 1; w < (int)(blockDim.x >> 6); ++w) v = c < 3 ? fminf(v, red[w][c]) : fmaxf(v, red[w][c]);
-        if (c < 3) atomicMin(&bbox[c], f2ord(v)); else atomicMax(&bbox[c], f2ord(v));
+        B.bbox_part[((size_t)cl * 64 + blockIdx.x) * 6 + c] = v;
     }
 }
 
-// one thread: grid geometry from the bbox and the device-side radius
-__global__ void grid_setup_kernel(const int32_t* __restrict__ bbox, const double* __restrict__ radius, int div, BallGrid* g,
-                                  const int32_t* __restrict__ skip)
+// one wave per set: grid geometry from the cloud's bounds and the device-side radius of the set's scale
+__global__ __launch_bounds__(64) void grid_setup_kernel(BallBatch B, int div)
 {
-    if (skip && *skip) return;
-    if (threadIdx.x != 0) return;
+    const int j = blockIdx.x, cl = j / B.S, sc = j - cl * B.S;
+    const int lane = threadIdx.x;
+    float v[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        float x = B.bbox_part[((size_t)cl * 64 + lane) * 6 + c];
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+            const float o = __shfl_xor(x, s, 64);
+            x = c < 3 ? fminf(x, o) : fmaxf(x, o);
+        }
+        v[c] = x;
+    }
+    if (lane != 0) return;
     float lo[3], hi[3], ext[3];
     float maxabs = 1.0f;
     for (int c = 0; c < 3; ++c) {
-        lo[c] = ord2f(bbox[c]);
-        hi[c] = ord2f(bbox[3 + c]);
+        lo[c] = v[c];
+        hi[c] = v[3 + c];
         if (!(hi[c] >= lo[c])) { lo[c] = 0.f; hi[c] = 0.f; }   // empty / NaN cloud
         ext[c] = hi[c] - lo[c];
         maxabs = fmaxf(maxabs, fmaxf(fabsf(lo[c]), fabsf(hi[c])));
     }
-    float r = (float)(*radius);
+    float r = (float)(B.radius[sc]);
     if (!(r > 0.f)) r = 0.f;
     // pad: covers the rounding of d2 (a hit can have |dx| up to r(1+5 eps)) and of fl(q -+ rpad)
     float rpad = r + (r * 1.0e-3f + 4.0e-7f * maxabs);
@@ -125,6 +156,7 @@ __global__ void grid_setup_kernel(const int32_t* __restrict__ bbox, const double
         if (tot <= BX_BALL_NCELL) break;
         h = h * 1.2599211f;
     }
+    BallGrid* g = B.grid + j;
     g->ox = lo[0]; g->oy = lo[1]; g->oz = lo[2];
     g->inv_h = 1.0f / h;
     g->rpad = rpad;
@@ -143,15 +175,23 @@ __device__ __forceinline__ int cell_coord(float x, float o, float inv_h, int d)
 // it).  Same-address device atomics serialise (~2 ns each measured with 100 hot cells), so when the grid fits the
 // 64 KiB LDS histogram each workgroup ranks its points with LDS atomics and reserves one range per (workgroup,
 // cell) with a single device atomic; finer grids (little contention) use the device atomic per point.
+// cnt[] is all zeros on entry: scan_apply_kernel clears what it has consumed (and bx_create zeroes it once).
 constexpr int COUNT_LDS_CELLS = 16384;
 constexpr int COUNT_PPT = 4;   // points per thread (register-resident between the two phases)
 
-__global__ __launch_bounds__(1024) void cell_count_kernel(const float* __restrict__ pts, int n, const BallGrid* __restrict__ g,
-                                                          int32_t* __restrict__ cnt, int2* __restrict__ cellrank,
-                                                          float4* __restrict__ pts4, const int32_t* __restrict__ skip)
+__global__ __launch_bounds__(1024) void cell_count_kernel(BallBatch B)
 {
-    if (skip && *skip) return;
     __shared__ int hist[COUNT_LDS_CELLS];
+    const int j = blockIdx.y, cl = j / B.S, sc = j - cl * B.S;
+    const int n = B.n[cl];
+    const int base = blockIdx.x * (1024 * COUNT_PPT);
+    if (base >= n) return;
+    const float* __restrict__ pts = B.pts[cl];
+    const int32_t* __restrict__ perm = B.perm[cl] ? B.perm[cl] + (size_t)sc * n : nullptr;
+    const BallGrid* __restrict__ g = B.grid + j;
+    int32_t* __restrict__ cnt = B.cnt + (size_t)j * B.st_cnt;
+    int2* __restrict__ cellrank = B.cellrank + (size_t)j * B.st_pts;
+    float4* __restrict__ pts4 = B.pts4 + (size_t)j * B.st_pts;
     const float ox = g->ox, oy = g->oy, oz = g->oz, ih = g->inv_h;
     const int dx = g->dx, dy = g->dy, dz = g->dz, ncells = g->ncells;
     const bool use_lds = ncells <= COUNT_LDS_CELLS;
@@ -161,13 +201,13 @@ __global__ __launch_bounds__(1024) void cell_count_kernel(const float* __restric
         __syncthreads();
     }
     int cell[COUNT_PPT], rank[COUNT_PPT];
-    const int base = blockIdx.x * (1024 * COUNT_PPT);
 #pragma unroll
     for (int u = 0; u < COUNT_PPT; ++u) {
         const int i = base + u * 1024 + tid;
         cell[u] = -1; rank[u] = 0;
         if (i < n) {
-            float x = pts[(size_t)i * 3], y = pts[(size_t)i * 3 + 1], z = pts[(size_t)i * 3 + 2];
+            const size_t src = perm ? (size_t)perm[i] : (size_t)i;
+            float x = pts[src * 3], y = pts[src * 3 + 1], z = pts[src * 3 + 2];
             pts4[i] = make_float4(x, y, z, 0.f);
             cell[u] = (cell_coord(z, oz, ih, dz) * dy + cell_coord(y, oy, ih, dy)) * dx + cell_coord(x, ox, ih, dx);
             rank[u] = use_lds ? atomicAdd(&hist[cell[u]], 1) : atomicAdd(&cnt[cell[u]], 1);
@@ -190,14 +230,14 @@ __global__ __launch_bounds__(1024) void cell_count_kernel(const float* __restric
 
 constexpr int SCAN_TILE = 2048;   // cells per 256-thread workgroup
 
-__global__ __launch_bounds__(256) void scan_sums_kernel(const int32_t* __restrict__ cnt, const BallGrid* __restrict__ g,
-                                                        int32_t* __restrict__ bsum, const int32_t* __restrict__ skip)
+__global__ __launch_bounds__(256) void scan_sums_kernel(BallBatch B)
 {
-    if (skip && *skip) return;
     __shared__ int ws[4];
+    const int j = blockIdx.y;
+    const int32_t* __restrict__ cnt = B.cnt + (size_t)j * B.st_cnt;
     const int base = blockIdx.x * SCAN_TILE;
     int s = 0;
-    if (base <= g->ncells) {
+    if (base <= (B.grid + j)->ncells) {
         const int4* p = reinterpret_cast<const int4*>(cnt + base) + threadIdx.x * 2;
         int4 a = p[0], b = p[1];
         s = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
@@ -205,19 +245,20 @@ __global__ __launch_bounds__(256) void scan_sums_kernel(const int32_t* __restric
     s = bx_wave_sum_i(s);
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) bsum[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+    if (threadIdx.x == 0) B.bsum[(size_t)j * B.st_bsum + blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
-// exclusive scan of cnt[0..ncells] -> start[0..ncells] (cnt[ncells] == 0, so start[ncells] == n)
-__global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restrict__ cnt, const BallGrid* __restrict__ g,
-                                                         const int32_t* __restrict__ bsum, int32_t* __restrict__ start,
-                                                         const int32_t* __restrict__ skip)
+// exclusive scan of cnt[0..ncells] -> start[0..ncells] (cnt[ncells] == 0, so start[ncells] == n); cnt is cleared behind the scan
+__global__ __launch_bounds__(256) void scan_apply_kernel(BallBatch B)
 {
-    if (skip && *skip) return;
     __shared__ int ws[4];
     __shared__ int boff;
+    const int j = blockIdx.y;
+    int32_t* __restrict__ cnt = B.cnt + (size_t)j * B.st_cnt;
+    int32_t* __restrict__ start = B.start + (size_t)j * B.st_cnt;
+    const int32_t* __restrict__ bsum = B.bsum + (size_t)j * B.st_bsum;
     const int base = blockIdx.x * SCAN_TILE;
-    if (base > g->ncells) return;
+    if (base > (B.grid + j)->ncells) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (wave == 0) {   // offset of this tile = sum of the preceding tiles (<= BX_BALL_NCELL / SCAN_TILE + 1 values)
         int v = 0;
@@ -225,8 +266,9 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restri
         v = bx_wave_sum_i(v);
         if (lane == 0) boff = v;
     }
-    const int4* p = reinterpret_cast<const int4*>(cnt + base) + tid * 2;
+    int4* p = reinterpret_cast<int4*>(cnt + base) + tid * 2;
     int4 a = p[0], b = p[1];
+    p[0] = make_int4(0, 0, 0, 0); p[1] = make_int4(0, 0, 0, 0);
     int tsum = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
     int inc = bx_wave_incl_scan_dpp(tsum);
     if (lane == 63) ws[wave] = inc;
@@ -240,17 +282,16 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restri
     o[0] = oa; o[1] = ob;
 }
 
-__global__ __launch_bounds__(256) void cell_scatter_kernel(const float4* __restrict__ pts4, int n, const int2* __restrict__ cellrank,
-                                                           const int32_t* __restrict__ start, float4* __restrict__ sorted,
-                                                           const int32_t* __restrict__ skip)
+__global__ __launch_bounds__(256) void cell_scatter_kernel(BallBatch B)
 {
-    if (skip && *skip) return;
+    const int j = blockIdx.y, cl = j / B.S;
+    const int n = B.n[cl];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int2 cr = cellrank[i];
-    float4 p = pts4[i];
+    const int2 cr = (B.cellrank + (size_t)j * B.st_pts)[i];
+    float4 p = (B.pts4 + (size_t)j * B.st_pts)[i];
     p.w = __int_as_float(i);
-    sorted[start[cr.x] + cr.y] = p;
+    (B.sorted + (size_t)j * B.st_pts)[(B.start + (size_t)j * B.st_cnt)[cr.x] + cr.y] = p;
 }
 
 struct F3 { float x, y, z; };   // 4-byte aligned triple: stores compile to global_store_dwordx3
@@ -264,11 +305,15 @@ constexpr int MAXROWS = 63;      // (y,z) cell rows kept in the per-wave row tab
 // sorted array minus its flat start (flat position v of row k lives in sorted[rs + v]).  Lane 63 carries {R, T} (T = sequence
 // length) or {-1, 0}: degenerate geometry, the query kernel walks the cells itself.  Doing this in its own launch takes one
 // dependent memory round trip, a prefix scan and all empty rows out of every query workgroup.
-__global__ __launch_bounds__(256) void ball_rows_kernel(const int32_t* __restrict__ start, const BallGrid* __restrict__ g,
-                                                        const float* __restrict__ kpts, int K, int2* __restrict__ rowtab,
-                                                        int4* __restrict__ chunktab, int trim, const int32_t* __restrict__ skip)
+__global__ __launch_bounds__(256) void ball_rows_kernel(BallBatch B, int trim)
 {
-    if (skip && *skip) return;
+    const int j_ = blockIdx.y, cl_ = j_ / B.S;
+    const int32_t* __restrict__ start = B.start + (size_t)j_ * B.st_cnt;
+    const BallGrid* __restrict__ g = B.grid + j_;
+    const float* __restrict__ kpts = B.kpts[cl_];
+    const int K = B.K;
+    int2* __restrict__ rowtab = B.rowtab + (size_t)j_ * B.st_tab;
+    int4* __restrict__ chunktab = B.chunktab + (size_t)j_ * B.st_tab;
     __shared__ int2 comp[4][64];
     __shared__ unsigned int cm[4][128];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -593,7 +638,7 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
 }
 
 template <int LOGC, int QW>
-int launch_query_w(bx_ctx* c, hipStream_t s, int K, const float* kpts, const double* radius, int P, int32_t* idx_out, float* patches_out)
+int launch_query_w(bx_ctx* c, hipStream_t s, int set, int K, const float* kpts, const double* radius, int P, int32_t* idx_out, float* patches_out)
 {
     const size_t lds = ((size_t)64 << LOGC) * 12 + (size_t)P * 4;   // bitmap | per-word prefix | ordered index list
     if (lds > 160 * 1024) { bx_set_error("bxk_ball_group: P=%d needs %zu B of LDS per keypoint (> 160 KiB)", P, lds); return BX_ERR_ARG; }
@@ -601,14 +646,17 @@ int launch_query_w(bx_ctx* c, hipStream_t s, int K, const float* kpts, const dou
         BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_kernel<LOGC, QW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         c->ball_attr_set |= 1 << (LOGC * 3 + QW / 2);
     }
-    hipLaunchKernelGGL((ball_query_kernel<LOGC, QW>), dim3(K), dim3(64 * QW), lds, s, c->ball_sorted, c->ball_start, c->ball_grid, c->ball_rowtab, c->ball_chunktab, c->ball_pts4, kpts, K,
+    const size_t j = (size_t)set;
+    hipLaunchKernelGGL((ball_query_kernel<LOGC, QW>), dim3(K), dim3(64 * QW), lds, s, c->ball_sorted + j * c->ball_st_pts,
+                       c->ball_start + j * c->ball_st_cnt, c->ball_grid + j, c->ball_rowtab + j * c->ball_st_tab,
+                       c->ball_chunktab + j * c->ball_st_tab, c->ball_pts4 + j * c->ball_st_pts, kpts, K,
                        radius, P, idx_out, patches_out, c->skip, getenv("BX_BALL_DEBUG") ? c->ball_dbg : nullptr);
     BX_LAUNCH_CHECK();
     return BX_OK;
 }
 
 template <int LOGC>
-int launch_query(bx_ctx* c, hipStream_t s, int K, const float* kpts, const double* radius, int P, int32_t* idx_out, float* patches_out)
+int launch_query(bx_ctx* c, hipStream_t s, int set, int K, const float* kpts, const double* radius, int P, int32_t* idx_out, float* patches_out)
 {
     // waves per keypoint: 4 for the large neighbourhoods (their candidate scan dominates), 1 for the small ones (the
     // per-keypoint chain of dependent memory round trips dominates and more independent workgroups hide it better)
@@ -617,9 +665,9 @@ int launch_query(bx_ctx* c, hipStream_t s, int K, const float* kpts, const doubl
     // measured (K = 5000, P = 1024): 4 waves win whenever the bitmap sweep is long (n > 32768: LOGC >= 4) or the neighbourhood is
     // large (hint from the radius threshold); 2 waves only for small neighbourhoods in small clouds
     const int w = forced ? forced : (LOGC >= 4 ? 4 : c->ball_waves_hint);
-    if (w >= 4) return launch_query_w<LOGC, 4>(c, s, K, kpts, radius, P, idx_out, patches_out);
-    if (w == 1) return launch_query_w<LOGC, 1>(c, s, K, kpts, radius, P, idx_out, patches_out);
-    return launch_query_w<LOGC, 2>(c, s, K, kpts, radius, P, idx_out, patches_out);
+    if (w >= 4) return launch_query_w<LOGC, 4>(c, s, set, K, kpts, radius, P, idx_out, patches_out);
+    if (w == 1) return launch_query_w<LOGC, 1>(c, s, set, K, kpts, radius, P, idx_out, patches_out);
+    return launch_query_w<LOGC, 2>(c, s, set, K, kpts, radius, P, idx_out, patches_out);
 }
 }  // namespace
 
@@ -649,38 +697,82 @@ int bx_permute_launch(hipStream_t s, const float* pts, const int32_t* perm, int 
     return BX_OK;
 }
 
+namespace {
+int ball_logc(int n)
+{
+    int logc = 3;
+    while (((size_t)64 << logc) * 64 < (size_t)n) ++logc;   // 64 lanes x C words x 64 bits >= n
+    return logc;
+}
+}  // namespace
+
+// Grids + row tables of `nclouds` clouds x S scales in six launches (see BallBatch).  clouds / perms / kpts: per cloud; perm[cl] is
+// [S][n] or nullptr (identity).  radius: device array of S doubles.
+int bxk_ball_prepare(bx_ctx* c, hipStream_t s, const float* const* clouds, const int* ns, const int32_t* const* perms,
+                     const float* const* kpts, int nclouds, int K, const double* radius, int S)
+{
+    if (K <= 0) return BX_OK;
+    if (nclouds < 1 || nclouds > 2 || S < 1 || nclouds * S > c->ball_nsets) {
+        bx_set_error("bxk_ball_prepare: %d clouds x %d scales exceed the context's %d grid sets", nclouds, S, c->ball_nsets);
+        return BX_ERR_ARG;
+    }
+    BallBatch B;
+    memset(&B, 0, sizeof(B));
+    int nmax = 0;
+    for (int cl = 0; cl < nclouds; ++cl) {
+        if (ns[cl] <= 0 || ns[cl] > c->p.max_points) { bx_set_error("bxk_ball_prepare: n=%d outside [1, max_points=%d]", ns[cl], c->p.max_points); return BX_ERR_ARG; }
+        if (ball_logc(ns[cl]) > 8) { bx_set_error("bxk_ball_prepare: cloud of %d points exceeds the 1M-point bitmap", ns[cl]); return BX_ERR_ARG; }
+        B.pts[cl] = clouds[cl]; B.perm[cl] = perms ? perms[cl] : nullptr; B.kpts[cl] = kpts[cl]; B.n[cl] = ns[cl];
+        nmax = ns[cl] > nmax ? ns[cl] : nmax;
+    }
+    B.S = S; B.nsets = nclouds * S; B.K = K; B.radius = radius;
+    B.bbox_part = c->ball_bbox_part; B.grid = c->ball_grid; B.cnt = c->ball_cnt; B.start = c->ball_start; B.bsum = c->ball_bsum;
+    B.cellrank = c->ball_cellrank; B.pts4 = c->ball_pts4; B.sorted = c->ball_sorted; B.rowtab = c->ball_rowtab; B.chunktab = c->ball_chunktab;
+    B.st_cnt = c->ball_st_cnt; B.st_bsum = c->ball_st_bsum; B.st_pts = c->ball_st_pts; B.st_tab = c->ball_st_tab;
+    const int nb = (nmax + 255) / 256;
+    const int nb4k = (nmax + 1024 * COUNT_PPT - 1) / (1024 * COUNT_PPT);
+    const int ntile = BX_BALL_NCELL / SCAN_TILE + 1;
+    hipLaunchKernelGGL(bbox_kernel, dim3(64, nclouds), dim3(1024), 0, s, B);
+    hipLaunchKernelGGL(grid_setup_kernel, dim3(B.nsets), dim3(64), 0, s, B, bx_ball_div());
+    hipLaunchKernelGGL(cell_count_kernel, dim3(nb4k, B.nsets), dim3(1024), 0, s, B);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(ntile, B.nsets), dim3(256), 0, s, B);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(ntile, B.nsets), dim3(256), 0, s, B);
+    hipLaunchKernelGGL(cell_scatter_kernel, dim3(nb, B.nsets), dim3(256), 0, s, B);
+    hipLaunchKernelGGL(ball_rows_kernel, dim3((K + 3) / 4, B.nsets), dim3(256), 0, s, B, bx_ball_trim());
+    BX_LAUNCH_CHECK();
+    return BX_OK;
+}
+
+// The query of one prepared set: n = size of its cloud, radius = device pointer to the radius of its scale.
+int bxk_ball_query(bx_ctx* c, hipStream_t s, int set, int n, const float* kpts, int K, const double* radius, int P,
+                   int32_t* idx_out, float* patches_out)
+{
+    if (K <= 0) return BX_OK;
+    if (P < 2) { bx_set_error("bxk_ball_query: P=%d", P); return BX_ERR_ARG; }
+    bx_prof_mark(c, s, 12, 1);
+    int rc = BX_OK;
+    switch (ball_logc(n)) {
+    case 3: rc = launch_query<3>(c, s, set, K, kpts, radius, P, idx_out, patches_out); break;
+    case 4: rc = launch_query<4>(c, s, set, K, kpts, radius, P, idx_out, patches_out); break;
+    case 5: rc = launch_query<5>(c, s, set, K, kpts, radius, P, idx_out, patches_out); break;
+    case 6: rc = launch_query<6>(c, s, set, K, kpts, radius, P, idx_out, patches_out); break;
+    case 7: rc = launch_query<7>(c, s, set, K, kpts, radius, P, idx_out, patches_out); break;
+    default: rc = launch_query<8>(c, s, set, K, kpts, radius, P, idx_out, patches_out); break;
+    }
+    bx_prof_mark(c, s, 12, 0);
+    return rc;
+}
+
+// stage entry point (bx_ball_group): one already permuted cloud, one radius
 int bxk_ball_group(bx_ctx* c, hipStream_t s, const float* pts_perm, int n, const float* kpts, int K, const double* radius,
                    int P, int32_t* idx_out, float* patches_out)
 {
     if (K <= 0) return BX_OK;
     if (n <= 0 || P < 2) { bx_set_error("bxk_ball_group: n=%d P=%d", n, P); return BX_ERR_ARG; }
-    if (n > c->p.max_points) { bx_set_error("bxk_ball_group: n=%d exceeds the context's max_points=%d", n, c->p.max_points); return BX_ERR_ARG; }
-    int logc = 3;
-    while (((size_t)64 << logc) * 64 < (size_t)n) ++logc;   // 64 lanes x C words x 64 bits >= n
-    if (logc > 8) { bx_set_error("bxk_ball_group: cloud of %d points exceeds the 1M-point bitmap", n); return BX_ERR_ARG; }
-    const int nb = (n + 255) / 256;
-    const int nb4k = (n + 1024 * COUNT_PPT - 1) / (1024 * COUNT_PPT);
-    const int ntile = BX_BALL_NCELL / SCAN_TILE + 1;
-    const int32_t* skip = c->skip;
-    hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, s, c->ball_bbox, skip);
-    hipLaunchKernelGGL(bbox_kernel, dim3(nb4k < 64 ? nb4k : 64), dim3(1024), 0, s, pts_perm, n, c->ball_bbox, skip);
-    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(64), 0, s, c->ball_bbox, radius, bx_ball_div(), c->ball_grid, skip);
-    BX_HIP(hipMemsetAsync(c->ball_cnt, 0, sizeof(int32_t) * (size_t)ntile * SCAN_TILE, s));
-    hipLaunchKernelGGL(cell_count_kernel, dim3(nb4k), dim3(1024), 0, s, pts_perm, n, c->ball_grid, c->ball_cnt, c->ball_cellrank, c->ball_pts4, skip);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(ntile), dim3(256), 0, s, c->ball_cnt, c->ball_grid, c->ball_bsum, skip);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(ntile), dim3(256), 0, s, c->ball_cnt, c->ball_grid, c->ball_bsum, c->ball_start, skip);
-    hipLaunchKernelGGL(cell_scatter_kernel, dim3(nb), dim3(256), 0, s, c->ball_pts4, n, c->ball_cellrank, c->ball_start, c->ball_sorted, skip);
-    hipLaunchKernelGGL(ball_rows_kernel, dim3((K + 3) / 4), dim3(256), 0, s, c->ball_start, c->ball_grid, kpts, K, c->ball_rowtab, c->ball_chunktab, bx_ball_trim(), skip);
-    bx_prof_mark(c, s, 12, 1);
-    int rc = BX_OK;
-    switch (logc) {
-    case 3: rc = launch_query<3>(c, s, K, kpts, radius, P, idx_out, patches_out); break;
-    case 4: rc = launch_query<4>(c, s, K, kpts, radius, P, idx_out, patches_out); break;
-    case 5: rc = launch_query<5>(c, s, K, kpts, radius, P, idx_out, patches_out); break;
-    case 6: rc = launch_query<6>(c, s, K, kpts, radius, P, idx_out, patches_out); break;
-    case 7: rc = launch_query<7>(c, s, K, kpts, radius, P, idx_out, patches_out); break;
-    default: rc = launch_query<8>(c, s, K, kpts, radius, P, idx_out, patches_out); break;
-    }
-    bx_prof_mark(c, s, 12, 0);
-    return rc;
+    const float* cl[1] = {pts_perm};
+    const float* kp[1] = {kpts};
+    const int ns[1] = {n};
+    int rc = bxk_ball_prepare(c, s, cl, ns, nullptr, kp, 1, K, radius, 1);
+    if (rc != BX_OK) return rc;
+    return bxk_ball_query(c, s, 0, n, kpts, K, radius, P, idx_out, patches_out);
 }

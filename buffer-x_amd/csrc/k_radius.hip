@@ -48,8 +48,11 @@ __global__ __launch_bounds__(256) void radius_hist_kernel(const float* __restric
 }
 
 // prefix sums + the literal bisection loop, one workgroup
+struct BisectThr { double t[BX_MAX_SCALES]; int n; };
+
+// the bisections of all scales of a pair share the histogram: one launch, thread i < nthr runs the loop of threshold i
 __global__ __launch_bounds__(1024) void radius_bisect_kernel(const unsigned long long* __restrict__ hist, long long n_orig,
-                                                             int nk, double threshold, double* des_r_out)
+                                                             int nk, BisectThr thr, double* des_r_out)
 {
     __shared__ unsigned long long cum[NB];
     __shared__ unsigned long long part[1024];
@@ -73,7 +76,8 @@ __global__ __launch_bounds__(1024) void radius_bisect_kernel(const unsigned long
         if (b < NB) { run += hist[b]; cum[b] = run; }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if ((int)threadIdx.x < thr.n) {
+        const double threshold = thr.t[threadIdx.x];
         const double tol = 0.01;
         double low = 0.0, high = 5.0, des_r = 0.0;
         float den = (float)((double)n_orig * (double)nk);
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(1024) void radius_bisect_kernel(const unsigned long
             else break;
         }
         double r100 = rint(des_r * 100.0);
-        *des_r_out = r100 / 100.0;
+        des_r_out[threadIdx.x] = r100 / 100.0;
     }
 }
 }  // namespace
@@ -105,10 +109,18 @@ int bxk_radius_hist(bx_ctx* c, hipStream_t s, const float* pts, int n_pts, const
     return BX_OK;
 }
 
-int bxk_radius_bisect(bx_ctx* c, hipStream_t s, int64_t n_orig, int nk, double threshold, double* des_r_out)
+int bxk_radius_bisect_all(bx_ctx* c, hipStream_t s, int64_t n_orig, int nk, const double* thresholds_host, int nthr, double* des_r_out)
 {
-    hipLaunchKernelGGL(radius_bisect_kernel, dim3(1), dim3(1024), 0, s, c->rad_hist, (long long)n_orig, nk,
-                       threshold, des_r_out);
+    if (nthr < 1 || nthr > BX_MAX_SCALES) { bx_set_error("bxk_radius_bisect_all: %d thresholds", nthr); return BX_ERR_ARG; }
+    BisectThr t;
+    t.n = nthr;
+    for (int i = 0; i < BX_MAX_SCALES; ++i) t.t[i] = i < nthr ? thresholds_host[i] : 0.0;
+    hipLaunchKernelGGL(radius_bisect_kernel, dim3(1), dim3(1024), 0, s, c->rad_hist, (long long)n_orig, nk, t, des_r_out);
     BX_LAUNCH_CHECK();
     return BX_OK;
+}
+
+int bxk_radius_bisect(bx_ctx* c, hipStream_t s, int64_t n_orig, int nk, double threshold, double* des_r_out)
+{
+    return bxk_radius_bisect_all(c, s, n_orig, nk, &threshold, 1, des_r_out);
 }

@@ -211,7 +211,7 @@ class Context:
         _chk(self.lib.bx_load_weights(self.handle, C.byref(w)), "bx_load_weights")
 
     PROF_TAGS = ["fps", "radius", "neighbour_gather", "patch_features", "desc_conv", "desc_head", "mutual", "pose_net",
-                 "consensus", "ransac", "refine", "permute", "neighbour_gather_query_kernel"]
+                 "consensus", "ransac", "refine", "permute", "neighbour_gather_query_kernel", "neighbour_grid_build"]
 
     def profile_enable(self, on=True):
         _chk(self.lib.bx_profile_enable(self.handle, C.c_int32(int(on))), "bx_profile_enable")

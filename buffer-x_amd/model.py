@@ -139,7 +139,7 @@ class BufferX(nn.Module):
         if timing:   # seconds, same three buckets as models/BUFFERX.py:310-316,466
             pr = ctx.profile_read()
             ms = lambda *tags: sum(pr[t][0] for t in tags)
-            times = [ms("fps", "radius", "permute", "neighbour_gather", "patch_features", "desc_conv", "desc_head", "mutual") / 1e3,
+            times = [ms("fps", "radius", "permute", "neighbour_grid_build", "neighbour_gather", "patch_features", "desc_conv", "desc_head", "mutual") / 1e3,
                      ms("pose_net", "consensus") / 1e3, ms("ransac", "refine") / 1e3]
         pose = np.array(res.pose, np.float64).reshape(4, 4)
         if cfg.test.pose_refine is True:

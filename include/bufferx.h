@@ -113,8 +113,9 @@ int64_t bx_workspace_bytes(const bx_ctx *ctx);
  * is synchronised bx_profile_read() adds up elapsed milliseconds / launch counts per stage tag and clears the
  * event list.  Tags: 0 fps, 1 radius, 2 neighbour-gather (ball_group), 3 patch features, 4 Desc conv stack,
  * 5 desc head, 6 mutual matching, 7 CostNet + soft-argmax, 8 hypotheses + consensus, 9 RANSAC, 10 refinement,
- * 11 permute, 12 the neighbour-gather query kernel alone (inside tag 2).  ms_out / count_out: HOST arrays of
- * BX_PROF_TAGS entries.                                                                                   */
+ * 11 permute (stage entry point only: the whole-pair path permutes on the fly), 12 the neighbour-gather query kernel alone
+ * (inside tag 2), 13 the batched grid + row-table build of all (cloud, scale) sets of a pair (once per pair; tag 2 then holds
+ * the query launches only).  ms_out / count_out: HOST arrays of BX_PROF_TAGS entries.                     */
 #define BX_PROF_TAGS 16
 int bx_profile_enable(bx_ctx *ctx, int32_t on);
 int bx_profile_read(bx_ctx *ctx, double *ms_out, int32_t *count_out);
