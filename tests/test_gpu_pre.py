@@ -115,3 +115,13 @@ def test_random_perm_matches_oracle(pctx, n):
         assert np.array_equal(np.sort(got), np.arange(n))
     a, b = pctx.random_perm(max(n, 2), 1).cpu().numpy(), pctx.random_perm(max(n, 2), 2).cpu().numpy()
     assert n < 64 or not np.array_equal(a, b)
+
+
+def test_voxel_downsample_hand_computed(pctx):
+    """the hand-computed Open3D VoxelDownSample vector of tests/test_oracle_pre.py (points on voxel faces, negative coordinates,
+    min-bound offset) through bx_pre_voxel_downsample"""
+    from test_oracle_pre import VOXEL_KAT_PTS, VOXEL_KAT_OUT
+    out, cnt = pctx.pre_voxel_downsample(VOXEL_KAT_PTS, 0.5)
+    m, status = (int(v) for v in cnt.cpu().numpy())
+    assert status == 0 and m == len(VOXEL_KAT_OUT)
+    assert np.array_equal(out[:m].cpu().numpy(), VOXEL_KAT_OUT)

@@ -150,3 +150,53 @@ def test_corrupt_files_never_crash(tmp_path, ing):
         except (lib.BxError, MemoryError, ValueError):
             err += 1
     assert ok + err == 400 and err > 50
+
+
+# ---------------------------------------------------------------------------------------------------- hand-assembled known answers
+# tests/golden/io_kat/*: files assembled byte by byte from the PLY 1.0 / PCD 0.7 format descriptions by tests/golden/io_kat/make_kat.py,
+# which uses neither oracle/io_oracle.py's writers nor the product -- the expected coordinates are the literals below.
+KAT_XYZ = np.array([(0.5, -1.25, 2.0), (1.0, 0.0, -0.75), (-3.5, 4.25, 0.125), (100.0, -0.0625, 7.0), (-8.0, 16.0, -32.0)], np.float32)
+KAT_FILES = ["kat_ascii.ply", "kat_le_faces_last.ply", "kat_be_faces_first.ply", "kat_double_be_crlf.ply",
+             "kat_ascii.pcd", "kat_binary.pcd", "kat_compressed.pcd"]
+
+
+@pytest.mark.parametrize("name", KAT_FILES)
+def test_known_answer_files(ing, name):
+    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "io_kat", name)
+    assert ing.probe(f) == 5
+    got = ing.read_point_cloud(f)
+    assert got.dtype == np.float32 and np.array_equal(got, KAT_XYZ)
+    ref = IO.read_ply(f) if name.endswith(".ply") else IO.read_pcd(f)      # the format restatement is pinned by the same files
+    assert np.array_equal(ref, KAT_XYZ)
+
+
+def test_known_answer_files_are_what_the_recipe_makes(tmp_path):
+    """the committed bytes == the output of the byte-level recipe (so the files cannot drift from their documented construction)"""
+    import importlib.util
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "io_kat")
+    spec = importlib.util.spec_from_file_location("make_kat", os.path.join(d, "make_kat.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    made = {"kat_ascii.ply": mk.ply_ascii(), "kat_le_faces_last.ply": mk.ply_binary("little", False),
+            "kat_be_faces_first.ply": mk.ply_binary("big", True), "kat_double_be_crlf.ply": mk.ply_double_be_crlf(),
+            "kat_ascii.pcd": mk.pcd_ascii(), "kat_binary.pcd": mk.pcd_binary(), "kat_compressed.pcd": mk.pcd_compressed()}
+    for name, data in made.items():
+        assert open(os.path.join(d, name), "rb").read() == data, name
+
+
+@pytest.mark.parametrize("count", [-1, 200, 2**31 - 1])
+def test_ply_corrupt_list_length_is_rejected(tmp_path, ing, count):
+    """a list length that the file cannot hold (negative, or larger than the rest of the body) is an error, not a loop or a backwards seek"""
+    import struct
+    from bufferx_amd import lib
+    hdr = (b"ply\nformat binary_little_endian 1.0\nelement face 1\nproperty list int int vertex_indices\n"
+           b"element vertex 1\nproperty float x\nproperty float y\nproperty float z\nend_header\n")
+    f = str(tmp_path / "bad_list.ply")
+    open(f, "wb").write(hdr + struct.pack("<i3i", count, 0, 1, 2) + struct.pack("<3f", 1.0, 2.0, 3.0))
+    with pytest.raises(lib.BxError):
+        ing.read_point_cloud(f)
+    fa = str(tmp_path / "bad_list_ascii.ply")
+    open(fa, "wb").write(b"ply\nformat ascii 1.0\nelement vertex 1\nproperty list uchar int junk\nproperty float x\nproperty float y\n"
+                         b"property float z\nend_header\n" + str(count).encode() + b" 1 2 3 1.0 2.0 3.0\n")
+    with pytest.raises(lib.BxError):
+        ing.read_point_cloud(fa)

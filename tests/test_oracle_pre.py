@@ -58,3 +58,31 @@ def test_voxel_down_sample_properties():
     # a voxel size larger than the cloud collapses it to its mean
     one = PO.voxel_down_sample(pts, 10.0)
     assert one.shape == (1, 3) and np.allclose(one[0], pts.astype(np.float64).mean(0), atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------- hand-computed known answer
+# Open3D 0.18 PointCloud::VoxelDownSample: origin = min_bound - voxel/2, index = floor((p - origin) / voxel), output = mean of the
+# members.  Every number below is a multiple of 1/16 (exact in binary32 / binary64), so the expected centroids were worked out by
+# hand: voxel = 0.5, min_bound = (-1.25, -0.5, -0.25), origin = (-1.5, -0.75, -0.5);
+#   p0 (-1.25, 0, 0)        -> (0.5, 1.5, 1.0)   -> voxel (0,1,1)
+#   p1 (-1.0, 0.25, 0)      -> (1.0, 2.0, 1.0)   -> voxel (1,2,1)      x and y exactly ON a voxel face: the upper voxel
+#   p2 (-0.75, 0, 0.25)     -> (1.5, 1.5, 1.5)   -> voxel (1,1,1)
+#   p3 (-0.5, 0, 0)         -> (2.0, 1.5, 1.0)   -> voxel (2,1,1)      on a face again
+#   p4 (1, 1, 1)            -> (5.0, 3.5, 3.0)   -> voxel (5,3,3)
+#   p5 (1.125, 1.125, 1)    -> (5.25, 3.75, 3.0) -> voxel (5,3,3)      joins p4
+#   p6 (-1.25, -0.5, -0.25) -> (0.5, 0.5, 0.5)   -> voxel (0,0,0)      the min-bound corner: half a voxel inside the grid
+#   p7 (-0.875, .125, .125) -> (1.25, 1.75, 1.25)-> voxel (1,1,1)      joins p2
+VOXEL_KAT_PTS = np.array([(-1.25, 0, 0), (-1.0, 0.25, 0), (-0.75, 0, 0.25), (-0.5, 0, 0), (1, 1, 1), (1.125, 1.125, 1),
+                          (-1.25, -0.5, -0.25), (-0.875, 0.125, 0.125)], np.float32)
+VOXEL_KAT_OUT = np.array([(-1.25, 0, 0), (-1.0, 0.25, 0), (-0.8125, 0.0625, 0.1875), (-0.5, 0, 0), (1.0625, 1.0625, 1.0),
+                          (-1.25, -0.5, -0.25)], np.float32)          # voxels in order of first appearance
+
+
+def test_voxel_down_sample_hand_computed():
+    from oracle import pre_oracle as PO
+    out = PO.voxel_down_sample(VOXEL_KAT_PTS, 0.5)
+    assert np.array_equal(out, VOXEL_KAT_OUT)
+    # as a set it does not depend on the emission order (Open3D's is that of an unordered_map)
+    shuffled = VOXEL_KAT_PTS[[6, 3, 5, 0, 7, 1, 4, 2]]
+    got = PO.voxel_down_sample(shuffled, 0.5)
+    assert sorted(map(tuple, got.tolist())) == sorted(map(tuple, VOXEL_KAT_OUT.tolist()))
