@@ -105,7 +105,7 @@ void carve(bx_ctx* c, char* base, size_t* total)
     c->inlier_ind = cv.take<int32_t>(SK);
     c->rad_hist = cv.take<unsigned long long>(8200);
     c->fps_dist = nullptr;
-    c->fps_slots = cv.take<unsigned long long>(2 * 2 * 16 * 5);
+    c->fps_slots = cv.take<unsigned long long>(2 * 2 * 64 * 5);      // k_fps.hip: [cloud][parity][FPS_MAX_G][5]
     c->ransac_inl = cv.take<int32_t>(BX_RANSAC_BATCH);
     c->ransac_err = cv.take<double>(BX_RANSAC_BATCH);
     c->ransac_T = cv.take<double>((size_t)BX_RANSAC_BATCH * 12);
@@ -370,7 +370,15 @@ static int create_impl(bx_ctx* c, int device_id)
         double r = 5.0 * (double)m / 8192.0;
         thr[m] = (float)(r * r);
     }
-    return upload(&c->d_rad_thr, thr.data(), thr.size());
+    if ((rc = upload(&c->d_rad_thr, thr.data(), thr.size())) != BX_OK) return rc;
+    if (p.pose_estimator == 1) {
+        if (!(p.kiss_resolution > 0.0)) { bx_set_error("bx_create: kiss_resolution must be positive"); return BX_ERR_ARG; }
+        c->kiss_max_C = p.num_fps * p.num_scales;
+        const size_t kb = bxk_kiss_workspace_bytes(c->kiss_max_C);
+        hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&c->kiss_ws), kb);
+        if (e2 != hipSuccess) { c->kiss_ws = nullptr; bx_set_error("bx_create: KISS-Matcher workspace hipMalloc(%zu) failed: %s", kb, hipGetErrorString(e2)); return BX_ERR_HIP; }
+    } else if (p.pose_estimator != 0) { bx_set_error("bx_create: pose_estimator must be 0 (ransac) or 1 (kiss_matcher)"); return BX_ERR_ARG; }
+    return BX_OK;
 }
 
 int bx_create(int device_id, const bx_params* params, bx_ctx** out)
@@ -421,6 +429,7 @@ int bx_destroy(bx_ctx* c)
         delete v;
     }
     (void)hipFree(c->arena);
+    (void)hipFree(c->kiss_ws);
     (void)hipFree(c->d_centres); (void)hipFree(c->d_rot); (void)hipFree(c->d_rowc); (void)hipFree(c->d_rad_thr);
     (void)hipFree(c->d_pnt_w); (void)hipFree(c->d_pnt_b); (void)hipFree(c->d_pool_w1); (void)hipFree(c->d_pool_b1); (void)hipFree(c->d_pool_w2); (void)hipFree(c->d_pool_b2);
     for (int i = 0; i < BX_NDESC; ++i) { (void)hipFree(c->desc[i].W); (void)hipFree(c->desc[i].W32); (void)hipFree(c->desc[i].b); (void)hipFree(c->desc[i].lrow); (void)hipFree(c->desc[i].lrow2); (void)hipFree(c->desc[i].obase); (void)hipFree(c->desc[i].toff); }
@@ -655,6 +664,14 @@ int bx_ransac(bx_ctx* c, void* stream, const float* ss, const float* tt, const i
     return bxk_ransac(c, (hipStream_t)stream, ss, tt, corr, C_dev, max_C, seed, T_out, info_out, nullptr);
 }
 
+int bx_kiss_solve(bx_ctx* c, void* stream, const float* ss, const float* tt, const int32_t* corr, const int32_t* C_dev, int32_t max_C,
+                  double* T_out, int32_t* info_out)
+{
+    BX_ENTER(c, false);
+    if (!ss || !tt || !corr || !C_dev) { bx_set_error("bx_kiss_solve: null argument"); return BX_ERR_ARG; }
+    return bxk_kiss(c, (hipStream_t)stream, ss, tt, corr, C_dev, max_C, T_out, info_out, nullptr);
+}
+
 int bx_refine(bx_ctx* c, void* stream, const float* ss, const float* tt, const int32_t* M_dev, int32_t max_M, float* T_io,
               int32_t* iters_out)
 {
@@ -826,15 +843,19 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
             if (c->cap.counts) hipLaunchKernelGGL(cap_counts_kernel, dim3(1), dim3(64), 0, s, st, c->cap.counts, (double*)nullptr);
         }
         if (early && i == 0) {
-            if ((rc = bxk_ransac(c, s, c->ss_cat, c->tt_cat, c->inlier_ind, &st->C, K, bx_mix64(seed, 0x5AC0000ULL + ransac_calls), nullptr, nullptr, nullptr)) != BX_OK) return rc;
+            if (p.pose_estimator == 1) rc = bxk_kiss(c, s, c->ss_cat, c->tt_cat, c->inlier_ind, &st->C, K, nullptr, nullptr, nullptr);
+            else rc = bxk_ransac(c, s, c->ss_cat, c->tt_cat, c->inlier_ind, &st->C, K, bx_mix64(seed, 0x5AC0000ULL + ransac_calls), nullptr, nullptr, nullptr);
+            if (rc != BX_OK) return rc;
             ++ransac_calls;
             hipLaunchKernelGGL(early_exit_kernel, dim3(1), dim3(64), 0, s, st, p.early_exit_min_inliers);
         }
     }
     // final pose estimation unless the early exit was taken (models/BUFFERX.py:449-457)
     { ProfScope ps(c, s, 9);
-    if ((rc = bxk_ransac(c, s, c->ss_cat, c->tt_cat, c->inlier_ind, &st->C, S * K, bx_mix64(seed, 0x5AC0000ULL + ransac_calls), nullptr, nullptr,
-                         early ? &st->done : nullptr)) != BX_OK) return rc; }
+    if (p.pose_estimator == 1) rc = bxk_kiss(c, s, c->ss_cat, c->tt_cat, c->inlier_ind, &st->C, S * K, nullptr, nullptr, early ? &st->done : nullptr);
+    else rc = bxk_ransac(c, s, c->ss_cat, c->tt_cat, c->inlier_ind, &st->C, S * K, bx_mix64(seed, 0x5AC0000ULL + ransac_calls), nullptr, nullptr,
+                         early ? &st->done : nullptr);
+    if (rc != BX_OK) return rc; }
     c->skip = nullptr;
     if (c->cap_on && c->cap.T_ransac) hipLaunchKernelGGL(cap_counts_kernel, dim3(1), dim3(64), 0, s, st, (int32_t*)nullptr, c->cap.T_ransac);
     if (p.pose_refine) {

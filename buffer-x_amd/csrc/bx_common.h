@@ -161,6 +161,8 @@ struct bx_ctx {
     int32_t* err_flag;                  // device error flag
     const int32_t* skip;                // device flag: non-zero => pipeline kernels return immediately (early exit)
     struct bx_lane* lane;               // optional: orders the MFMA-heavy sections of the pairs of several contexts (bx_attach_lane)
+    char* kiss_ws;                      // KISS-Matcher workspace (k_kiss.hip), allocated when params.pose_estimator == 1
+    int kiss_max_C;
     void* pre;                          // bx_pre_ws* (k_pre.hip): workspace of the pre-processing entry points, reserved on demand
     int conv_cap[2][BX_NPOSE];          // persistent-grid size of every conv layer on THIS device (0 = not set up yet)
     int conv32_cap[BX_NDESC];           // the same for the 32x32x2 kernels (k_conv32.hip)
@@ -206,6 +208,9 @@ int bxk_consensus(bx_ctx* c, hipStream_t s, const float* R, const float* t, cons
                   const int32_t* M_dev, int max_M, int32_t* inlier_out, int32_t* count_out, int32_t* best_out);
 int bxk_ransac(bx_ctx* c, hipStream_t s, const float* ss, const float* tt, const int32_t* corr, const int32_t* C_dev,
                int max_C, uint64_t seed, double* T_out, int32_t* info_out, const int32_t* skip_flag);
+size_t bxk_kiss_workspace_bytes(int max_C);
+int bxk_kiss(bx_ctx* c, hipStream_t s, const float* ss, const float* tt, const int32_t* corr, const int32_t* C_dev, int max_C,
+             double* T_out, int32_t* info_out, const int32_t* skip_flag);
 int bxk_pre_reserve(bx_ctx* c, int64_t max_points);
 void bxk_pre_release(bx_ctx* c);
 int bxk_pre_voxel_downsample(bx_ctx* c, hipStream_t s, const float* pts, int n, double voxel_size, float* out, int32_t* count_out);

@@ -17,14 +17,16 @@
 //   * G > 1: workgroups exchange their winner {key, x, y, z} through 8-byte {epoch, value} granules
 //     written with agent-scope relaxed (sc1, write-through) stores and polled with agent-scope relaxed
 //     loads -- the "R2 granule" hand-off of the CDNA4 guide: no fence, placement independent, spins
-//     bounded.  Slots are double-buffered by iteration parity and zeroed by a memset node before launch.
+//     bounded.  Slots are double-buffered by iteration parity and zeroed by a memset node before launch.  All G workgroups of a
+//     cloud must be resident at once (they wait for each other): G <= 64 per cloud, 2 clouds, 256 CUs.
 #include "bx_common.h"
 
 namespace {
 
 constexpr int FPS_THREADS = 1024;
 constexpr int FPS_WAVES = FPS_THREADS / 64;
-constexpr int FPS_MAX_G = 16;
+constexpr int FPS_MAX_G = 64;            // 64 workgroups x 16 384 points = 1 048 576 points per cloud (the neighbour bitmap's limit too)
+constexpr int FPS_NR = (5 * FPS_MAX_G + 63) / 64;   // polling rounds: one granule per lane and round
 constexpr int FPS_MAX_CLOUDS = 2;
 constexpr unsigned FPS_SPIN_LIMIT = 1u << 24;
 
@@ -183,11 +185,13 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                         __hip_atomic_store(my + q, ((unsigned long long)ep << 32) | v[q], __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
                 }
-                // poll all G records (lanes 0..5G-1, one granule each; 5G <= 80 -> two rounds max)
-                unsigned val[2] = {0, 0};
+                // poll all G records (one granule per lane and round; rounds beyond 5G granules are skipped: G is uniform)
+                unsigned val[FPS_NR];
                 bool fail = false;
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
+                for (int r = 0; r < FPS_NR; ++r) {
+                    val[r] = 0;
+                    if (r * 64 >= 5 * G) continue;
                     int q = lane + r * 64;
                     bool act = q < 5 * G;
                     unsigned long long* gp = slots + (size_t)par * FPS_MAX_G * 5 + q;
@@ -209,8 +213,11 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                 long long bestk = (long long)0x8000000000000000LL;
                 float ox = 0.f, oy = 0.f, oz = 0.f;
                 auto granule = [&](int qq) -> unsigned {    // wave-uniform index: v_readlane, no LDS crossbar
-                    return qq < 64 ? (unsigned)__builtin_amdgcn_readlane((int)val[0], qq)
-                                   : (unsigned)__builtin_amdgcn_readlane((int)val[1], qq - 64);
+                    unsigned v = 0;
+#pragma unroll
+                    for (int r = 0; r < FPS_NR; ++r)
+                        if ((qq >> 6) == r) v = (unsigned)__builtin_amdgcn_readlane((int)val[r], qq & 63);   // uniform branch
+                    return v;
                 };
                 for (int w = 0; w < G; ++w) {
                     const int q0 = 5 * w;

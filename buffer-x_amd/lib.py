@@ -23,7 +23,8 @@ class BxParams(C.Structure):
                 ("search_radius_thresholds", C.c_double * BX_MAX_SCALES),
                 ("dist_th", C.c_double), ("inlier_th", C.c_double), ("similar_th", C.c_double),
                 ("confidence", C.c_double), ("iter_n", C.c_int32), ("enable_early_exit", C.c_int32),
-                ("early_exit_min_inliers", C.c_int32), ("pose_refine", C.c_int32), ("max_points", C.c_int32)]
+                ("early_exit_min_inliers", C.c_int32), ("pose_refine", C.c_int32), ("max_points", C.c_int32),
+                ("pose_estimator", C.c_int32), ("kiss_resolution", C.c_double)]
 
 
 class BxWeights(C.Structure):
@@ -53,7 +54,7 @@ EXPORTS = ["bx_create", "bx_destroy", "bx_last_error", "bx_load_weights", "bx_wo
            "bx_set_capture",
            "bx_profile_enable", "bx_profile_read", "bx_debug_read",
            "bx_fps", "bx_radius", "bx_permute", "bx_ball_group", "bx_patch_features", "bx_desc_net", "bx_conv_layer",
-           "bx_mutual", "bx_pose_net", "bx_hypotheses", "bx_consensus", "bx_ransac", "bx_refine",
+           "bx_mutual", "bx_pose_net", "bx_hypotheses", "bx_consensus", "bx_ransac", "bx_kiss_solve", "bx_refine",
            "bx_pre_reserve", "bx_pre_voxel_downsample", "bx_pre_pca", "bx_random_perm",
            "bx_lane_create", "bx_lane_destroy", "bx_attach_lane",
            "bx_io_probe", "bx_io_read_xyz", "bx_prefetch_create", "bx_prefetch_submit", "bx_prefetch_wait", "bx_prefetch_release",
@@ -117,6 +118,11 @@ def params_from_cfg(cfg, max_points):
     p.early_exit_min_inliers = int(cfg.match.get("early_exit_min_inliers", 15))
     p.pose_refine = int(cfg.test.pose_refine is True)
     p.max_points = int(max_points)
+    est = cfg.match.get("pose_estimator", "ransac")
+    if est not in ("ransac", "kiss_matcher"):
+        raise ValueError(f"Unknown pose estimator: {est}")           # models/pose_estimator.py:48
+    p.pose_estimator = 1 if est == "kiss_matcher" else 0
+    p.kiss_resolution = float(cfg.match.get("kiss_resolution", 0.3))
     return p
 
 
@@ -395,6 +401,17 @@ class Context:
         info = self._empty((2,), t.int32)
         _chk(self.lib.bx_ransac(self.handle, self._stream(), self._p(ss), self._p(tt), self._p(corr), self._p(C_dev),
                                 C.c_int32(max_C), C.c_uint64(seed & (2**64 - 1)), self._p(T), self._p(info)), "bx_ransac")
+        return T, info
+
+    def kiss_solve(self, ss, tt, corr, C_dev, max_C):
+        """KISS-Matcher back-end on the correspondences corr (context created with cfg.match.pose_estimator == "kiss_matcher")"""
+        t = self.torch
+        ss, tt = self._dev(ss, t.float32), self._dev(tt, t.float32)
+        corr, C_dev = self._dev(corr, t.int32), self._dev(C_dev, t.int32)
+        T = self._empty((16,), t.float64)
+        info = self._empty((4,), t.int32)
+        _chk(self.lib.bx_kiss_solve(self.handle, self._stream(), self._p(ss), self._p(tt), self._p(corr), self._p(C_dev),
+                                    C.c_int32(max_C), self._p(T), self._p(info)), "bx_kiss_solve")
         return T, info
 
     def refine(self, ss, tt, M_dev, max_M, T):

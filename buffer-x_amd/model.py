@@ -70,9 +70,8 @@ class BufferX(nn.Module):
         self.config = config
         if config.stage != "test":
             raise NotImplementedError("bufferx_amd.BufferX implements the inference path only (config.stage == 'test')")
-        if config.match.get("pose_estimator", "ransac") != "ransac":
-            # the reference falls back to RANSAC when kiss_matcher is not importable (models/pose_estimator.py:74-82)
-            print("Warning: only the RANSAC pose estimator is implemented; falling back to RANSAC.")
+        if config.match.get("pose_estimator", "ransac") not in ("ransac", "kiss_matcher"):
+            raise ValueError(f"Unknown pose estimator: {config.match.pose_estimator}")      # models/pose_estimator.py:48
         self.Desc = _Desc()
         self.Pose = _Pose()
         self._ctx = None
@@ -85,7 +84,8 @@ class BufferX(nn.Module):
         key = (device_index, cfg.patch.num_fps, cfg.patch.num_points_per_patch, cfg.patch.num_scales,
                tuple(cfg.patch.search_radius_thresholds), cfg.match.dist_th, cfg.match.inlier_th, cfg.match.similar_th,
                cfg.match.confidence, cfg.match.iter_n, bool(cfg.match.get("enable_early_exit", True)),
-               cfg.match.get("early_exit_min_inliers", 15), cfg.test.pose_refine is True)
+               cfg.match.get("early_exit_min_inliers", 15), cfg.test.pose_refine is True,
+               cfg.match.get("pose_estimator", "ransac"), cfg.match.get("kiss_resolution", 0.3))
         cap = self._max_points or 0
         if self._ctx is not None and self._ctx_key == key and n_max <= self._ctx_cap:
             return self._ctx

@@ -64,6 +64,8 @@ typedef struct bx_params {
     int32_t early_exit_min_inliers;       /* cfg.match.early_exit_min_inliers */
     int32_t pose_refine;                  /* cfg.test.pose_refine */
     int32_t max_points;                   /* workspace sizing: largest cloud this context will see */
+    int32_t pose_estimator;               /* cfg.match.pose_estimator: 0 = "ransac", 1 = "kiss_matcher" (utils/test_args.py:74-80) */
+    double kiss_resolution;               /* cfg.match.kiss_resolution (KISSMatcherConfig(resolution), models/pose_estimator.py:61) */
 } bx_params;
 
 /* BatchNorm-folded weights in kernel layout, HOST pointers (buffer-x_amd/weights.py: fold_and_pack).
@@ -223,6 +225,14 @@ int bx_consensus(bx_ctx *ctx, void *stream, const float *R, const float *t, cons
  * info_out device int32 [2] = {num_inliers, iterations visited}.                                */
 int bx_ransac(bx_ctx *ctx, void *stream, const float *ss, const float *tt, const int32_t *corr, const int32_t *C_dev,
               int32_t max_C, uint64_t seed, double *T_out, int32_t *info_out);
+
+/* PoseEstimator._estimate_kiss_matcher (models/pose_estimator.py:50-82): KISSMatcher(KISSMatcherConfig(kiss_resolution)).solve on
+ * the correspondences corr[0..*C_dev) -- maximum-k-core pruning of the compatibility graph, GNC-TLS rotation, component-wise TLS
+ * translation; restated from the published algorithm (the package is not vendored by the reference: see oracle/bx_oracle.c).
+ * The context must have been created with params.pose_estimator = 1.  T_out device double [16]; info_out device int32 [4] =
+ * {final inliers (get_num_final_inliers), core size, rotation inliers, GNC iterations}.                                    */
+int bx_kiss_solve(bx_ctx *ctx, void *stream, const float *ss, const float *tt, const int32_t *corr, const int32_t *C_dev,
+                  int32_t max_C, double *T_out, int32_t *info_out);
 
 /* BufferX.post_refinement + rigid_transform_3d (models/BUFFERX.py:522-603).  T_io device float [16];
  * iters_out device int32 [1] (nullable).                                                        */

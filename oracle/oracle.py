@@ -251,3 +251,16 @@ def ref_batch_neighbors(queries, supports, radius_):
     cs = C.c_longlong(0)
     mc = r.ref_batch_neighbors(_p(q), C.c_int(len(q)), _p(s), C.c_int(len(s)), C.c_float(radius_), C.byref(cs))
     return int(mc), int(cs.value)
+
+
+def kiss_solve(ss, tt, corr, resolution, robin_gain=1.0, solver_gain=0.75):
+    """KISS-Matcher solve() on the correspondences corr (restated from the published algorithm, see bx_oracle.c; parity unpinned
+    against the `kiss_matcher` package, which is not under /root/reference).  -> (T 4x4 float64, info[4] = final inliers, core size,
+    rotation inliers, GNC iterations)."""
+    ss, tt, corr = _f(ss), _f(tt), _i(corr)
+    T = np.zeros((4, 4), np.float64)
+    info = np.zeros(4, np.int32)
+    lib().bxo_kiss_solve.restype = C.c_int
+    lib().bxo_kiss_solve(_p(ss), _p(tt), _p(corr), C.c_int(len(corr)), C.c_double(robin_gain * resolution),
+                         C.c_double(solver_gain * resolution), _p(T), _p(info))
+    return T, info

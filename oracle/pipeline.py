@@ -52,6 +52,9 @@ def pose_forward(s_equi, t_equi, s_mids, t_mids, pw, cfg, cap=None, tag=""):
 
 
 def estimate_pose(ss, tt, inlier_ind, cfg, seed, call):
+    if cfg.match.get("pose_estimator", "ransac") == "kiss_matcher":      # models/pose_estimator.py:43-44
+        T, info = O.kiss_solve(ss, tt, inlier_ind, cfg.match.get("kiss_resolution", 0.3))
+        return T, int(info[0]), int(info[3])
     T, n, it = O.ransac(ss, tt, inlier_ind, cfg.match.dist_th, cfg.match.similar_th, cfg.match.confidence,
                         cfg.match.iter_n, O.mix64(seed, 0x5AC0000 + call))
     return T, n, it

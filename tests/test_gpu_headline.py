@@ -185,7 +185,8 @@ def test_conv_layers_group_walk(bx, packed, oracle, monkeypatch):
     W = bx.weights
     cfg = _headline_cfg(bx)
     rng = np.random.default_rng(3)
-    for cap_env in ("48", None):
+    for cap_env, conv32 in (("48", "0"), (None, "0"), ("48", "1"), (None, "1")):      # BX_CONV32=1: the 32x32x2 kernels of k_conv32.hip
+        monkeypatch.setenv("BX_CONV32", conv32)
         if cap_env:
             monkeypatch.setenv("BX_CONV_PERSIST_CAP", cap_env)
         else:
@@ -205,7 +206,7 @@ def test_conv_layers_group_walk(bx, packed, oracle, monkeypatch):
                 ref = oracle.conv(lib.chunked_to_logical(_np(x[ts])), tap, L["W"], L["b"], L["relu"])
                 assert np.array_equal(lib.chunked_to_logical(_np(y[ts])), ref), ("desc", l, cap_env)
                 x = y
-            if cap_env is None:
+            if cap_env is None or conv32 == "1":
                 continue
             # Pose: layer 0 consumes the implicit cost volume (bx_pose_net); layers 1..9 through bx_conv_layer
             units = 1400

@@ -31,7 +31,7 @@ def _np(t):
 
 
 # ------------------------------------------------------------------ FPS (row 2/3)
-@pytest.mark.parametrize("n,m", [(700, 64), (3000, 256), (9000, 256), (20000, 200), (40000, 160), (66000, 96)])
+@pytest.mark.parametrize("n,m", [(700, 64), (3000, 256), (9000, 256), (20000, 200), (40000, 160), (66000, 96), (300000, 48)])   # 300k: 19 workgroups, above the former 262 144-point cap
 def test_fps_exact(ctx, oracle, n, m):
     rng = np.random.default_rng(n)
     xyz = (rng.random((n, 3), np.float32) * 4 - 1).astype(np.float32)

@@ -94,3 +94,53 @@ def test_jacobi_and_kabsch(tmp_path_factory):
     assert np.allclose(R.reshape(3, 3), Rref, atol=1e-9)
     # rank < 2 is rejected
     assert L.t_kabsch(_p(np.zeros(9)), _p(R)) == 0
+
+
+# ------------------------------------------------------------------ KISS-Matcher back-end (restated; oracle/bx_oracle.c bxo_kiss_solve)
+def _kiss_case(seed, M, outlier_frac, noise, structured=0.0):
+    rng = np.random.default_rng(seed)
+    ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+    ang = rng.uniform(0.2, 1.2)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    Rg = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+    tg = rng.uniform(-1, 1, 3)
+    s = (rng.random((M, 3)) * 6).astype(np.float32)
+    g = (s @ Rg.T + tg + noise * rng.standard_normal((M, 3))).astype(np.float32)
+    bad = rng.random(M) < outlier_frac
+    g[bad] = (rng.random((int(bad.sum()), 3)) * 6).astype(np.float32)
+    if structured > 0:                       # a second, smaller consistent motion: must lose against the larger one
+        k = int(M * structured)
+        R2 = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1.0]])
+        g[:k] = (s[:k] @ R2.T + np.array([3.0, 0.5, -1.0])).astype(np.float32)
+        bad[:k] = True
+    return s, g, Rg, tg, bad
+
+
+def test_kiss_solve_recovers_pose_under_outliers():
+    from oracle import oracle as O
+    for seed, M, frac, structured in ((0, 500, 0.7, 0.0), (1, 300, 0.5, 0.15), (2, 800, 0.8, 0.0)):
+        s, g, Rg, tg, bad = _kiss_case(seed, M, frac, 0.02, structured)
+        T, info = O.kiss_solve(s, g, np.arange(M, dtype=np.int32), 0.3)
+        good = int((~bad).sum())
+        assert info[1] >= 0.9 * good and info[0] >= 0.8 * good, (info, good)
+        assert np.abs(T[:3, :3] - Rg).max() < 5e-3 and np.abs(T[:3, 3] - tg).max() < 2e-2
+        assert abs(np.linalg.det(T[:3, :3]) - 1) < 1e-9
+
+
+def test_kiss_solve_gnc_iterates_and_degenerate_inputs():
+    from oracle import oracle as O
+    # noise well above the bound for a third of the "inliers": the core keeps some of them, GNC has to down-weight them
+    s, g, Rg, tg, bad = _kiss_case(5, 400, 0.3, 0.02)
+    rng = np.random.default_rng(9)
+    loose = np.flatnonzero(~bad)[::3]
+    g[loose] += (0.35 * rng.standard_normal((len(loose), 3))).astype(np.float32)
+    T, info = O.kiss_solve(s, g, np.arange(400, dtype=np.int32), 0.3)
+    assert info[3] > 1 and info[2] <= info[1] and info[0] <= info[2]
+    assert np.abs(T[:3, :3] - Rg).max() < 2e-2
+    # fewer than two correspondences / a single pair / collinear sources: identity or a finite pose, never a crash
+    for C in (0, 1):
+        T, info = O.kiss_solve(s, g, np.arange(C, dtype=np.int32), 0.3)
+        assert np.array_equal(T, np.eye(4)) and info[0] == 0
+    line = np.stack([np.linspace(0, 5, 50), np.zeros(50), np.zeros(50)], 1).astype(np.float32)
+    T, info = O.kiss_solve(line, line + np.float32(1.0), np.arange(50, dtype=np.int32), 0.3)
+    assert np.isfinite(T).all()
