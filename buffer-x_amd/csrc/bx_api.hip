@@ -117,15 +117,16 @@ void carve(bx_ctx* c, char* base, size_t* total)
     c->ball_st_cnt = (size_t)BX_BALL_NCELL + 2 * 2048;
     c->ball_st_bsum = BX_BALL_NCELL / 2048 + 2;
     c->ball_st_pts = (NMAX + 63) & ~(size_t)63;
-    c->ball_st_tab = KM * 64;
+    c->ball_st_tab = KM * 256;                    // k_ball.hip NPMAX pieces per keypoint
+    c->ball_st_num = KM;
     c->ball_bbox_part = cv.take<float>(2 * 64 * 6);
     c->ball_grid = cv.take<BallGrid>(NS);
     c->ball_cnt = cv.take<int32_t>(NS * c->ball_st_cnt);
     c->ball_start = cv.take<int32_t>(NS * c->ball_st_cnt);
     c->ball_bsum = cv.take<int32_t>(NS * c->ball_st_bsum);
     c->ball_cellrank = cv.take<int2>(NS * c->ball_st_pts);
-    c->ball_rowtab = cv.take<int2>(NS * c->ball_st_tab);
-    c->ball_chunktab = cv.take<int4>(NS * c->ball_st_tab);
+    c->ball_ptab = cv.take<int2>(NS * c->ball_st_tab);
+    c->ball_pnum = cv.take<int32_t>(NS * c->ball_st_num);
     c->ball_pts4 = cv.take<float4>(NS * c->ball_st_pts);
     c->ball_sorted = cv.take<float4>(NS * c->ball_st_pts);
     c->ball_dbg = cv.take<long long>(64 * 8);
@@ -793,7 +794,7 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
     // every scale's radius up front (the bisections share the histogram: one launch), then the grids + candidate row tables of
     // all 2 x S (cloud, scale) sets in one batch of six launches; the per-scale permutation is applied on the fly
     { ProfScope ps(c, s, 1); if ((rc = bxk_radius_bisect_all(c, s, (int64_t)ns[big], NK, p.search_radius_thresholds, S, st->des_r)) != BX_OK) return rc; }
-    { ProfScope ps(c, s, 13); if ((rc = bxk_ball_prepare(c, s, clouds, ns, perms, c->kpts, 2, K, st->des_r, S)) != BX_OK) return rc; }
+    { ProfScope ps(c, s, 13); if ((rc = bxk_ball_prepare(c, s, clouds, ns, perms, c->kpts, 2, K, st->des_r, S, p.search_radius_thresholds)) != BX_OK) return rc; }
 
     const bool early = p.enable_early_exit != 0;
     int ransac_calls = 0;

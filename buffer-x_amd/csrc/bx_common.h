@@ -144,14 +144,15 @@ struct bx_ctx {
     // neighbour-gather grid (k_ball.hip)
     // ... one "set" per (cloud, scale) of a pair: ball_nsets = 2 * num_scales; element j of a per-set array at base + j * stride
     int ball_nsets;
-    size_t ball_st_cnt, ball_st_bsum, ball_st_pts, ball_st_tab;
+    size_t ball_st_cnt, ball_st_bsum, ball_st_pts, ball_st_tab, ball_st_num;
     float* ball_bbox_part;              // [2][64][6] per-block bounds of the two clouds
     BallGrid* ball_grid;                // [nsets]
     int32_t *ball_cnt, *ball_start;     // [nsets][BX_BALL_NCELL + 2 tiles]; cnt is all zeros between launches
     int32_t* ball_bsum;                 // [nsets] per scan tile
     int2* ball_cellrank;                // [nsets][max_points]
-    int2* ball_rowtab;                  // [nsets][num_fps][64] per-keypoint candidate row table (ball_rows_kernel)
-    int4* ball_chunktab;                // [nsets][num_fps][64] per-keypoint chunk table {row-boundary mask lo, hi, rows in front, 0}
+    int2* ball_ptab;                    // [nsets][num_fps][256] per-keypoint candidate pieces {first slot, count} (ball_rows_kernel)
+    int32_t* ball_pnum;                 // [nsets][num_fps] pieces per keypoint, -1: degenerate geometry
+    int ball_logpw[2 * BX_MAX_SCALES];  // piece width (log2) of every prepared set
     float4 *ball_pts4, *ball_sorted;    // [nsets][max_points] {x,y,z,0} in permuted order / {x,y,z,bits(i)} sorted by cell
     long long ball_attr_set;
     int ball_waves_hint;                // waves per keypoint of the next neighbour-gather launch (0 = default 2)
@@ -185,7 +186,7 @@ int bxk_radius_bisect(bx_ctx* c, hipStream_t s, int64_t n_orig, int nk, double t
 int bxk_ball_group(bx_ctx* c, hipStream_t s, const float* pts_perm, int n, const float* kpts, int K, const double* radius,
                    int P, int32_t* idx_out, float* patches_out);
 int bxk_ball_prepare(bx_ctx* c, hipStream_t s, const float* const* clouds, const int* ns, const int32_t* const* perms,
-                     const float* const* kpts, int nclouds, int K, const double* radius, int S);
+                     const float* const* kpts, int nclouds, int K, const double* radius, int S, const double* pw_hint);
 int bxk_ball_query(bx_ctx* c, hipStream_t s, int set, int n, const float* kpts, int K, const double* radius, int P,
                    int32_t* idx_out, float* patches_out);
 int bxk_radius_bisect_all(bx_ctx* c, hipStream_t s, int64_t n_orig, int nk, const double* thresholds_host, int nthr, double* des_r_out);

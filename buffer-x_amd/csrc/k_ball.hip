@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 
+
 namespace {
 
 __global__ void permute_kernel(const float* __restrict__ pts, const int32_t* __restrict__ perm, int n, float* __restrict__ out,
@@ -68,9 +69,10 @@ struct BallBatch {
     int32_t *cnt, *start, *bsum;
     int2* cellrank;
     float4 *pts4, *sorted;
-    int2* rowtab;
-    int4* chunktab;
-    size_t st_cnt, st_bsum, st_pts, st_tab;
+    int2* ptab;                 // [nsets][K][NPMAX] candidate pieces {first slot in the sorted array, count <= 1 << logpw}
+    int32_t* pnum;              // [nsets][K] number of pieces, -1: degenerate geometry (the query walks the cells itself)
+    size_t st_cnt, st_bsum, st_pts, st_tab, st_num;
+    int logpw[BX_MAX_SCALES];   // piece width of scale i: 64 / 16 / 8 candidates by the expected length of a cell row
 };
 
 // per-block partial bounds of a cloud (64 blocks x 2 clouds, no atomics, no initialisation launch)
@@ -296,26 +298,27 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(BallBatch B)
 
 struct F3 { float x, y, z; };   // 4-byte aligned triple: stores compile to global_store_dwordx3
 
-constexpr int QU = 8;            // candidate loads in flight per lane
 constexpr int MAXROWS = 63;      // (y,z) cell rows kept in the per-wave row table (one lane each)
 
-// Row tables of all keypoints, one wave per keypoint.  The candidates of a keypoint are the points of the (y,z) cell rows around
-// it, every row trimmed to the chord of the ball; the non-empty rows are laid end to end into ONE flat candidate sequence.
-// Lane k < R gets {rs, pe} of the k-th non-empty row: pe = the row's end offset in the flat sequence, rs = its first slot in the
-// sorted array minus its flat start (flat position v of row k lives in sorted[rs + v]).  Lane 63 carries {R, T} (T = sequence
-// length) or {-1, 0}: degenerate geometry, the query kernel walks the cells itself.  Doing this in its own launch takes one
-// dependent memory round trip, a prefix scan and all empty rows out of every query workgroup.
+constexpr int NPMAX = 256;       // piece-table capacity per keypoint
+
+// Candidate pieces of all keypoints, one wave per keypoint.  The candidates of a keypoint are the points of the (y,z) cell rows
+// around it, every row trimmed to the chord of the ball (a row's x-cells are ONE contiguous range of the sorted array).  Rows are
+// cut into PIECES of at most PW = 1 << logpw consecutive slots; the query kernel then needs no position -> row arithmetic at all:
+// lane group g of an iteration takes piece (iteration, wave, g) = {first slot, count} and lane li of the group tests slot
+// first + li.  (Round 1 laid the rows end to end into one flat sequence and mapped 64-candidate chunks back to rows with bit-mask
+// tables: ~40 instructions of addressing per chunk, more than the distance test itself.)  PW follows the expected row length:
+// 64 at the 5 % scale (rows of ~50 candidates), 16 at 2 %, 8 at 0.5 % (rows of ~4).
 __global__ __launch_bounds__(256) void ball_rows_kernel(BallBatch B, int trim)
 {
-    const int j_ = blockIdx.y, cl_ = j_ / B.S;
+    const int j_ = blockIdx.y, cl_ = j_ / B.S, sc_ = j_ - cl_ * B.S;
     const int32_t* __restrict__ start = B.start + (size_t)j_ * B.st_cnt;
     const BallGrid* __restrict__ g = B.grid + j_;
     const float* __restrict__ kpts = B.kpts[cl_];
     const int K = B.K;
-    int2* __restrict__ rowtab = B.rowtab + (size_t)j_ * B.st_tab;
-    int4* __restrict__ chunktab = B.chunktab + (size_t)j_ * B.st_tab;
-    __shared__ int2 comp[4][64];
-    __shared__ unsigned int cm[4][128];
+    int2* __restrict__ ptab = B.ptab + (size_t)j_ * B.st_tab;
+    int32_t* __restrict__ pnum = B.pnum + (size_t)j_ * B.st_num;
+    const int logpw = B.logpw[sc_], PW = 1 << logpw;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wv;
     if (q >= K) return;
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(256) void ball_rows_kernel(BallBatch B, int trim)
     const int ny = yhi - ylo + 1, nz = zhi - zlo + 1;
     const int R0 = ny * nz;
     if (R0 > MAXROWS) {
-        rowtab[(size_t)q * 64 + lane] = make_int2(lane == 63 ? -1 : 0, lane == 63 ? 0 : 0x7fffffff);
+        if (lane == 0) pnum[q] = -1;
         return;
     }
     int st = 0, len = 0;
@@ -360,33 +363,17 @@ __global__ __launch_bounds__(256) void ball_rows_kernel(BallBatch B, int trim)
             len = start[rowc + xh + 1] - st;
         }
     }
-    // drop the empty rows (order kept), then the running end offsets
-    const unsigned long long live = __ballot(len > 0);
-    const int R = __popcll(live);
-    const int rank = __popcll(live & ((1ULL << lane) - 1ULL));
-    if (len > 0) comp[wv][rank] = make_int2(st, len);
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
-    int2 e = lane < R ? comp[wv][lane] : make_int2(0, 0);
-    const int inc = bx_wave_incl_scan_dpp(e.y);
-    const int T = __builtin_amdgcn_readlane(inc, 63);
-    int2 o = make_int2(e.x - (inc - e.y), lane < R ? inc : 0x7fffffff);
-    if (lane == 63) o = make_int2(R, T);
-    rowtab[(size_t)q * 64 + lane] = o;
-    // chunk table (T <= 4096: 64 chunks of 64 candidates): bit b of chunk j's mask = "a row ends at flat position 64 j + b"
-    // (position pe - 1), z = rows that ended in front of the chunk.  The row of flat position v = 64 j + l is then
-    // z_j + popcount(mask_j & lanes below l): two mbcnt instructions per chunk in the query kernel instead of a row walk.
-    if (T <= 4096) {
-        cm[wv][lane] = 0u; cm[wv][64 + lane] = 0u;
-        __builtin_amdgcn_wave_barrier();
-        if (lane < R) { const int pos = inc - 1; atomicOr(&cm[wv][pos >> 5], 1u << (pos & 31)); }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        const unsigned mlo = cm[wv][2 * lane], mhi = cm[wv][2 * lane + 1];
-        const int cnt = __popc(mlo) + __popc(mhi);
-        const int cinc = bx_wave_incl_scan_dpp(cnt);
-        chunktab[(size_t)q * 64 + lane] = make_int4((int)mlo, (int)mhi, cinc - cnt, 0);
+    // pieces of every row, laid out row after row (the order is immaterial: the hit bitmap restores the index order)
+    const int np = (len + PW - 1) >> logpw;
+    const int inc = bx_wave_incl_scan_dpp(np);
+    const int NP = __builtin_amdgcn_readlane(inc, 63);
+    if (NP > NPMAX) {                                        // very long candidate sequences: the query walks the cells itself
+        if (lane == 0) pnum[q] = -1;
+        return;
     }
+    int2* __restrict__ pq = ptab + (size_t)q * NPMAX + (inc - np);
+    for (int i = 0; i < np; ++i) pq[i] = make_int2(st + (i << logpw), min(PW, len - (i << logpw)));
+    if (lane == 0) pnum[q] = NP;
 }
 
 // QW waves per workgroup, ONE keypoint per workgroup (template parameter: 4 / 2 / 1 by the expected neighbourhood size)
@@ -401,19 +388,19 @@ __device__ __forceinline__ void set_hit(unsigned int* bm32, int i)
 // varies 3x between keypoints).  LOGC: log2 of the 64-bit bitmap words per 64 lanes (n <= 4096 << LOGC).
 // The kernel is VALU-issue bound (rocprofv3 SQ_INSTS_VALU: ~800 instructions per wave at 8 waves per SIMD), not memory bound:
 // the structure below is chosen for instruction count.
-//   1. candidates = the flat row sequence prepared by ball_rows_kernel, 64-candidate chunks dealt round-robin to the waves; the
-//      chunk -> row lookup is wave-uniform scalar code (readlane of the per-lane row table).
+//   1. candidates = the pieces prepared by ball_rows_kernel, staged in LDS and dealt round-robin to the lane groups of the waves;
+//      a lane's candidate is  piece.first + (lane & (PW - 1)):  no position -> row arithmetic.
 //   2. hits set their bit in an LDS bitmap (bit = permuted point index): this restores the index order the reference's
 //      ball_query scans in, whatever order the grid delivered the candidates in.
 //   3. rank of a hit = set bits below it = prefix[word] + popcount(word & below): when all candidates of the keypoint were held in
 //      registers (up to two blocks of QU chunks per wave: the common case) every hit computes its own rank and drops its index
 //      into list[rank] -- no per-bit loops; otherwise the owners of the bitmap words expand their bits in order.
 //   4. output: gather + mask arithmetic from the ordered list, 768 contiguous bytes per wave store.
-// LDS: bitmap (n/8 B) | per-word prefix (n/16 B) | list (4 P B).
+// LDS: bitmap (n/8 B) | per-word prefix (n/16 B) | list (4 P B) | piece table (8 NPMAX B).
 template <int LOGC, int QW>
 __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __restrict__ sorted, const int32_t* __restrict__ start,
-                                                        const BallGrid* __restrict__ g, const int2* __restrict__ rowtab,
-                                                        const int4* __restrict__ chunktab, const float4* __restrict__ pts4,
+                                                        const BallGrid* __restrict__ g, const int2* __restrict__ ptab,
+                                                        const int32_t* __restrict__ pnum, int logpw, const float4* __restrict__ pts4,
                                                         const float* __restrict__ kpts, int K,
                                                         const double* __restrict__ radius, int P, int32_t* __restrict__ idx_out,
                                                         float* __restrict__ patches, const int32_t* __restrict__ skip,
@@ -445,80 +432,57 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
         for (int s = 0; s < CW / 2; ++s) z[s] = make_ulonglong2(0ULL, 0ULL);
     }
 
-    const int2 rt = rowtab[(size_t)q * 64 + lane];          // prepared by ball_rows_kernel: {rs, pe}; lane 63: {R, T}
-    const int4 ct = chunktab[(size_t)q * 64 + lane];        // chunk j: {boundary mask lo, hi, rows in front} (valid when T <= 4096)
+    int2* ptl = reinterpret_cast<int2*>(smem + (size_t)NW64 * 12 + (((size_t)P * 4 + 7) & ~(size_t)7));   // [NPMAX] piece table of this keypoint
+    const int NP = __builtin_amdgcn_readfirstlane(pnum[q]);                          // -1: degenerate geometry
+    for (int i = tid; i < NP; i += QT) ptl[i] = ptab[(size_t)q * NPMAX + i];
     const float r = (float)(*radius);
     const float r2 = r * r;
     const float qx = kpts[(size_t)q * 3], qy = kpts[(size_t)q * 3 + 1], qz = kpts[(size_t)q * 3 + 2];
-    const int R = __builtin_amdgcn_readlane(rt.x, 63);     // -1: degenerate geometry
-    const int T = __builtin_amdgcn_readlane(rt.y, 63);
-    const int rs = rt.x;
-    const int pe = lane == 63 ? 0x7fffffff : rt.y;
     BX_TR(1);
-    __syncthreads();                                        // bitmap zeroed
-    if (tr) td[7] = T;
+    __syncthreads();                                        // bitmap zeroed, piece table staged
+    if (tr) td[7] = NP;
 
-    constexpr int NBLK = 2;                                 // register blocks (QU chunks per wave each) whose hits can rank themselves
-    const bool one_block = R >= 0 && T <= QT * QU * NBLK;   // uniform: every candidate is tested from a register that is kept
-    int hidx[QU * NBLK];                                    // one_block: index of the hit in slot (block, u), -1 otherwise
+    constexpr int MAXIT = 16;                               // iterations whose hits are kept in registers and rank themselves
+    const int GP = 64 >> logpw;                             // pieces per wave and iteration
+    const int nit = NP > 0 ? (NP + QW * GP - 1) / (QW * GP) : 0;   // uniform
+    const bool one_block = NP >= 0 && nit <= MAXIT;
+    int hidx[MAXIT];                                        // one_block: index of the hit of iteration it, -1 otherwise
 #pragma unroll
-    for (int u = 0; u < QU * NBLK; ++u) hidx[u] = -1;
-    if (R >= 0) {
-        int rb = 0;                                         // wave-uniform (SGPR): first row whose end lies beyond the chunk start
-        // one block: QU chunks per wave.  The loads go out back to back and are waited for once (a load under a DIVERGENT branch
-        // is waited for right behind its issue: the merge with the not-taken value needs the data); chunks beyond T are skipped
-        // by scalar branches, lanes beyond T read slot 0 (a valid point) and are masked in the test
-        auto scan_block = [&](int c0, int* hx) {
-            float4 c[QU];
+    for (int u = 0; u < MAXIT; ++u) hidx[u] = -1;
+    if (NP >= 0) {
+        const int grp = lane >> logpw, li = lane & ((1 << logpw) - 1);
+        // a batch of 4 iterations: the four table reads, then the four candidate loads go out back to back (a load under a
+        // divergent branch would be waited for right behind its issue), then the four tests
+        auto scan4 = [&](int it0, int* hx) {
+            float4 c[4];
+            bool ok[4];
 #pragma unroll
-            for (int u = 0; u < QU; ++u) {
-                const int vc = (c0 + u * QW + wave) * 64;   // uniform chunk start
-                const int v = vc + lane;
-                int addr = 0;
-                if (vc < T && T <= 4096) {                  // uniform: chunk table -> row of every lane without a walk
-                    const int cj = vc >> 6;
-                    const unsigned mlo = (unsigned)__builtin_amdgcn_readlane(ct.x, cj), mhi = (unsigned)__builtin_amdgcn_readlane(ct.y, cj);
-                    const int row = __builtin_amdgcn_readlane(ct.z, cj) + (int)__builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
-                    addr = __builtin_amdgcn_ds_bpermute(row << 2, rs) + v;
-                    addr = v < T ? addr : 0;
-                } else if (vc < T) {                        // uniform: long sequences walk the row table
-                    while (__builtin_amdgcn_readlane(pe, rb) <= vc) ++rb;
-                    addr = __builtin_amdgcn_readlane(rs, rb) + v;
-                    int k = rb;
-                    int pek = __builtin_amdgcn_readlane(pe, k);
-                    while (pek <= vc + 63) {                // uniform: a row boundary falls inside this chunk
-                        const int nrs = __builtin_amdgcn_readlane(rs, k + 1);
-                        addr = v >= pek ? nrs + v : addr;
-                        ++k;
-                        pek = __builtin_amdgcn_readlane(pe, k);
-                    }
-                    addr = v < T ? addr : 0;
-                }
-                // unconditional (a chunk beyond T re-reads slot 0): a load under a branch whose result merges with "not loaded"
-                // is waited for right behind its issue.  32-bit byte offset from the uniform base: ONE address VGPR (saddr form)
-                c[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sorted) + ((unsigned)addr << 4));
+            for (int u = 0; u < 4; ++u) {
+                const int pc = ((it0 + u) * QW + wave) * GP + grp;
+                int2 e = make_int2(0, 0);
+                if (pc < NP) e = ptl[pc];
+                ok[u] = li < e.y;
+                const unsigned addr = ok[u] ? (unsigned)(e.x + li) : 0u;     // lanes without a candidate re-read slot 0 (masked below)
+                c[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sorted) + (addr << 4));
             }
 #pragma unroll
-            for (int u = 0; u < QU; ++u) {
-                const int vc = (c0 + u * QW + wave) * 64;
-                if (vc < T) {                               // uniform
-                    const float ax = qx - c[u].x, ay = qy - c[u].y, az = qz - c[u].z;
-                    const float d2 = (ax * ax + ay * ay) + az * az;
-                    if (d2 < r2 && vc + lane < T) {
-                        const int i = __float_as_int(c[u].w);
-                        set_hit(bm32, i);
-                        hx[u] = i;
-                    }
+            for (int u = 0; u < 4; ++u) {
+                const float ax = qx - c[u].x, ay = qy - c[u].y, az = qz - c[u].z;
+                const float d2 = (ax * ax + ay * ay) + az * az;
+                if (d2 < r2 && ok[u]) {
+                    const int i = __float_as_int(c[u].w);
+                    set_hit(bm32, i);
+                    hx[u] = i;
                 }
             }
         };
         if (one_block) {
 #pragma unroll
-            for (int b = 0; b < NBLK; ++b)
-                if (b * QW * QU * 64 < T) scan_block(b * QW * QU, hidx + b * QU);      // uniform
+            for (int b = 0; b < MAXIT / 4; ++b)
+                if (b * 4 < nit) scan4(b * 4, hidx + b * 4);        // uniform
         } else {
-            int dump[QU];
-            for (int c0 = 0; c0 * 64 < T; c0 += QW * QU) scan_block(c0, dump);
+            int dump[4];
+            for (int it0 = 0; it0 < nit; it0 += 4) scan4(it0, dump);
         }
     } else {
         // degenerate geometry (cell edge << radius because of the 1024-cells-per-axis floor): plain nested walk
@@ -576,7 +540,7 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < QU * NBLK; ++u) {
+        for (int u = 0; u < MAXIT; ++u) {
             const int i = hidx[u];
             if (i >= 0) {
                 const int w = i >> 6;
@@ -640,7 +604,7 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
 template <int LOGC, int QW>
 int launch_query_w(bx_ctx* c, hipStream_t s, int set, int K, const float* kpts, const double* radius, int P, int32_t* idx_out, float* patches_out)
 {
-    const size_t lds = ((size_t)64 << LOGC) * 12 + (size_t)P * 4;   // bitmap | per-word prefix | ordered index list
+    const size_t lds = ((size_t)64 << LOGC) * 12 + (((size_t)P * 4 + 7) & ~(size_t)7) + (size_t)NPMAX * 8;   // bitmap | per-word prefix | ordered index list | pieces
     if (lds > 160 * 1024) { bx_set_error("bxk_ball_group: P=%d needs %zu B of LDS per keypoint (> 160 KiB)", P, lds); return BX_ERR_ARG; }
     if (lds > 64 * 1024 && !(c->ball_attr_set & (1LL << (LOGC * 3 + QW / 2)))) {
         BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_kernel<LOGC, QW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -648,8 +612,8 @@ int launch_query_w(bx_ctx* c, hipStream_t s, int set, int K, const float* kpts, 
     }
     const size_t j = (size_t)set;
     hipLaunchKernelGGL((ball_query_kernel<LOGC, QW>), dim3(K), dim3(64 * QW), lds, s, c->ball_sorted + j * c->ball_st_pts,
-                       c->ball_start + j * c->ball_st_cnt, c->ball_grid + j, c->ball_rowtab + j * c->ball_st_tab,
-                       c->ball_chunktab + j * c->ball_st_tab, c->ball_pts4 + j * c->ball_st_pts, kpts, K,
+                       c->ball_start + j * c->ball_st_cnt, c->ball_grid + j, c->ball_ptab + j * c->ball_st_tab,
+                       c->ball_pnum + j * c->ball_st_num, c->ball_logpw[set], c->ball_pts4 + j * c->ball_st_pts, kpts, K,
                        radius, P, idx_out, patches_out, c->skip, getenv("BX_BALL_DEBUG") ? c->ball_dbg : nullptr);
     BX_LAUNCH_CHECK();
     return BX_OK;
@@ -709,7 +673,7 @@ int ball_logc(int n)
 // Grids + row tables of `nclouds` clouds x S scales in six launches (see BallBatch).  clouds / perms / kpts: per cloud; perm[cl] is
 // [S][n] or nullptr (identity).  radius: device array of S doubles.
 int bxk_ball_prepare(bx_ctx* c, hipStream_t s, const float* const* clouds, const int* ns, const int32_t* const* perms,
-                     const float* const* kpts, int nclouds, int K, const double* radius, int S)
+                     const float* const* kpts, int nclouds, int K, const double* radius, int S, const double* pw_hint)
 {
     if (K <= 0) return BX_OK;
     if (nclouds < 1 || nclouds > 2 || S < 1 || nclouds * S > c->ball_nsets) {
@@ -727,8 +691,16 @@ int bxk_ball_prepare(bx_ctx* c, hipStream_t s, const float* const* clouds, const
     }
     B.S = S; B.nsets = nclouds * S; B.K = K; B.radius = radius;
     B.bbox_part = c->ball_bbox_part; B.grid = c->ball_grid; B.cnt = c->ball_cnt; B.start = c->ball_start; B.bsum = c->ball_bsum;
-    B.cellrank = c->ball_cellrank; B.pts4 = c->ball_pts4; B.sorted = c->ball_sorted; B.rowtab = c->ball_rowtab; B.chunktab = c->ball_chunktab;
-    B.st_cnt = c->ball_st_cnt; B.st_bsum = c->ball_st_bsum; B.st_pts = c->ball_st_pts; B.st_tab = c->ball_st_tab;
+    B.cellrank = c->ball_cellrank; B.pts4 = c->ball_pts4; B.sorted = c->ball_sorted; B.ptab = c->ball_ptab; B.pnum = c->ball_pnum;
+    B.st_cnt = c->ball_st_cnt; B.st_bsum = c->ball_st_bsum; B.st_pts = c->ball_st_pts; B.st_tab = c->ball_st_tab; B.st_num = c->ball_st_num;
+    for (int i = 0; i < S; ++i) {
+        // piece width by the share of the cloud a ball of this scale is expected to hold (its cell rows are ~1/40 of that): the
+        // percentage thresholds of the pair path (cfg.patch.search_radius_thresholds), 64 when unknown (stage entry point)
+        const double thr = pw_hint ? pw_hint[i] : 100.0;
+        const int lp = thr >= 3.5 ? 6 : (thr >= 1.0 ? 4 : 3);
+        B.logpw[i] = lp;
+        for (int cl = 0; cl < nclouds; ++cl) c->ball_logpw[cl * S + i] = lp;
+    }
     const int nb = (nmax + 255) / 256;
     const int nb4k = (nmax + 1024 * COUNT_PPT - 1) / (1024 * COUNT_PPT);
     const int ntile = BX_BALL_NCELL / SCAN_TILE + 1;
@@ -772,7 +744,7 @@ int bxk_ball_group(bx_ctx* c, hipStream_t s, const float* pts_perm, int n, const
     const float* cl[1] = {pts_perm};
     const float* kp[1] = {kpts};
     const int ns[1] = {n};
-    int rc = bxk_ball_prepare(c, s, cl, ns, nullptr, kp, 1, K, radius, 1);
+    int rc = bxk_ball_prepare(c, s, cl, ns, nullptr, kp, 1, K, radius, 1, nullptr);
     if (rc != BX_OK) return rc;
     return bxk_ball_query(c, s, 0, n, kpts, K, radius, P, idx_out, patches_out);
 }
