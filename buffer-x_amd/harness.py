@@ -163,7 +163,10 @@ class Runner:
             if cfg.test.pose_refine is True:
                 pose = pose.astype(np.float32)
             poses[i] = pose
-            rows[i] = evaluate.pack_state(i, pose, np.asarray(pairs[i]["relt_pose"], np.float64), r.num_inliers, r.num_mutual, r.num_inlier_ind,
+            # the reference's collate hands the ground truth over as float32 (dataset/dataloader.py:113), so RTE / RRE of a refined
+            # (float32) pose are float32 arithmetic in test.py:168-170: same dtype here, or the 6-decimal CSV cells can differ
+            gt = np.asarray(pairs[i]["relt_pose"], np.float32)
+            rows[i] = evaluate.pack_state(i, pose, gt, r.num_inliers, r.num_mutual, r.num_inlier_ind,
                                           r.scales_used, data_s, a.elapsed_time(b) / 1e3, [0.0, 0.0, 0.0],
                                           cfg.test.rte_thresh, cfg.test.rre_thresh)
             pending[c] = None

@@ -126,7 +126,11 @@ class BufferX(nn.Module):
         ctx = self._context(dev, max(src.shape[0], tgt.shape[0]))
         # the reference draws one permutation per Desc call from numpy's global RNG (models/patch_embedder.py:96),
         # in the order scale0-src, scale0-tgt, scale1-src, ... ; the same calls are made here so that a seeded
-        # np.random reproduces it.  Open3D's RANSAC is unseeded in the reference; the seed is drawn from np.random.
+        # np.random reproduces it.  LIMITS of that statement: (1) all S scales are drawn up front, the reference draws lazily and
+        # stops at an early exit (models/BUFFERX.py:424-439) -- with enable_early_exit the global NumPy stream diverges from the
+        # reference's after the first pair that exits early; (2) Open3D's RANSAC is unseeded in the reference, here the seed is one
+        # extra draw from np.random per pair, which shifts every later draw by one call.  A caller that needs the reference's
+        # stream beyond one pair must save / restore np.random's state around forward().
         ps, pt = [], []
         for _ in range(S):
             ps.append(np.random.choice(src.shape[0], src.shape[0], replace=False).astype(np.int32))

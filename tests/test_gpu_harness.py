@@ -66,7 +66,7 @@ def test_runner_matches_step_by_step(tmp_path, bx, packed):
             pose = np.array(res.pose, np.float64).reshape(4, 4).astype(np.float32)
             assert np.array_equal(pose, poses[i]), i
             assert rows[i, 4] == res.num_inliers and rows[i, 5] == res.num_mutual and rows[i, 7] == res.scales_used
-            assert rows[i, 2] == evaluate.compute_rte(pose, np.asarray(p["relt_pose"], np.float64))
+            assert rows[i, 2] == evaluate.compute_rte(pose, np.asarray(p["relt_pose"], np.float32))      # float32 ground truth like the reference collate
             assert np.array_equal(evaluate.state_pose(rows[i]), pose)
     finally:
         ctx.close()

@@ -30,3 +30,19 @@ for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         print("%-52s %6s %14s %12s" % ("kernel", "n", "mean_KiB", "avg_us"))
         for name, n, v, d in db.execute(q, (ctr,)):
             print("%-52s %6d %14.1f %12.2f" % (short(name)[:52], n, v, (d or 0) / 1e3))
+
+for f in sorted(glob.glob(os.path.join(root, "pmc_mfma", "*.db"))):
+    db = sqlite3.connect(f)
+    print("\n== rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE :: per kernel (busy = matrix-pipe busy share of the elapsed shader"
+          " cycles = MFMA_BUSY / (GUI_ACTIVE / 8 x 1024 SIMDs); GHz = GUI_ACTIVE / 8 / duration)")
+    rows = {}
+    q = "select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection group by kernel_name, counter_name"
+    for name, ctr, n, v, d in db.execute(q):
+        rows.setdefault(short(name), {})[ctr] = (n, v, d)
+    print("%-52s %6s %12s %8s %8s" % ("kernel", "n", "avg_us", "GHz", "busy"))
+    for k, c in sorted(rows.items(), key=lambda kv: -(kv[1].get("GRBM_GUI_ACTIVE", (0, 0, 0))[1] or 0) * (kv[1].get("GRBM_GUI_ACTIVE", (0, 0, 0))[0] or 0)):
+        g, m = c.get("GRBM_GUI_ACTIVE"), c.get("SQ_VALU_MFMA_BUSY_CYCLES")
+        if not g or not m or m[1] <= 0:
+            continue
+        cyc = g[1] / 8.0
+        print("%-52s %6d %12.2f %8.3f %8.3f" % (k[:52], g[0], (g[2] or 0) / 1e3, cyc / (g[2] or 1), m[1] / (cyc * 1024.0)))
