@@ -9,7 +9,7 @@ txt = open(sys.argv[1]).read()
 sec = {}
 cur = None
 for line in txt.splitlines():
-    if line.startswith("== rocprofv3 --pmc"):
+    if line.startswith("== rocprofv3 --pmc FETCH_SIZE") or line.startswith("== rocprofv3 --pmc WRITE_SIZE"):
         cur = "FETCH" if "--pmc FETCH_SIZE" in line else "WRITE"
         sec[cur] = {}
     elif line.startswith("== "):
