@@ -274,6 +274,9 @@ def main():
                 "mean_scales_used": round(mean_scales, 3),
                 "early_exit_taken": "%d/%d" % (sum(u["scales_used"] < S for u in us), len(us))}
         nmean = float(np.mean([dp["n"][0] + dp["n"][1] for dp in dpairs]) / 2)
+        # launches that did work: with the early exit taken the kernels of the later scales return at once (device-side skip
+        # flag) but are still bracketed by events -- per-launch averages are taken over the scales that ran
+        ran = mean_scales / S
         pmc = profile_json("pmc_traffic")
         busy = profile_json("mfma_busy")
         # --- dominant kernel: Desc conv stack (8 MFMA launches per cloud per scale)
@@ -281,6 +284,7 @@ def main():
         flops_per_stack = 2.0 * DESC_CONV_MMAC_PER_PATCH * 1e6 * K
         roof = None
         if conv_n:
+            conv_n = max(1, int(round(conv_n * ran)))
             ach = flops_per_stack / (conv_ms / conv_n * 1e-3) / 1e12
             roof = {"kernel": "conv_kernel<...> x8 (Cylindrical_Net stack, f32 MFMA)", "bound": "mfma",
                     "achieved": round(ach, 3), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
@@ -296,6 +300,7 @@ def main():
         pose_ms, pose_n = stages.get("pose_net", (0.0, 0))
         roof_cn = None
         if pose_n:
+            pose_n = max(1, int(round(pose_n * ran)))
             fl = 2.0 * COSTNET_MMAC_PER_MATCH * 1e6 * mean_m
             ach = fl / (pose_ms / pose_n * 1e-3) / 1e12
             roof_cn = {"kernel": "cost_l1_kernel + conv_kernel x9 + soft_argmax (CostNet)", "bound": "mfma", "achieved": round(ach, 3),
@@ -313,6 +318,7 @@ def main():
             nbytes = 12.0 * nmean + 12.0 * K + 4.0 * K * P + 12.0 * K * P
             # every launch of the stage: the batched grid + row-table build (six launches per PAIR, all 2 x S sets at once) and
             # one ball_query_kernel per (cloud, scale); hipEvent brackets on the kernels' stream
+            ng_n = max(1, int(round(ng_n * ran)))
             stage_ms = (ng_ms + gb_ms) / ng_n
             ach = nbytes / (stage_ms * 1e-3) / 1e9
             kach = nbytes / (ng_ms / ng_n * 1e-3) / 1e9

@@ -213,6 +213,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                 long long bestk = (long long)0x8000000000000000LL;
                 float ox = 0.f, oy = 0.f, oz = 0.f;
                 auto granule = [&](int qq) -> unsigned {    // wave-uniform index: v_readlane, no LDS crossbar
+                    if (5 * G <= 64) return (unsigned)__builtin_amdgcn_readlane((int)val[0], qq);   // G <= 12: one polling round
                     unsigned v = 0;
 #pragma unroll
                     for (int r = 0; r < FPS_NR; ++r)
