@@ -59,6 +59,21 @@ __global__ __launch_bounds__(256) void ransac_eval_kernel(const float* __restric
 #pragma unroll
         for (int c = 0; c < 3; ++c) { a[j][c] = (double)ss[(size_t)sidx * 3 + c]; b[j][c] = (double)tt[(size_t)sidx * 3 + c]; }
     }
+    // CorrespondenceCheckerBasedOnEdgeLength FIRST: it needs no transformation, rejects most random triples, and a rejected
+    // hypothesis then skips the binary64 Jacobi of the Umeyama fit (the accepted set is the same in either order: a hypothesis
+    // must pass every check; at confidence 1.0 all 50 000 iterations run and the fit was 7.4 ms per pair)
+    {
+        bool edge_ok = true;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = i + 1; j < 3; ++j) {
+                double ds = sqrt(((a[i][0] - a[j][0]) * (a[i][0] - a[j][0]) + (a[i][1] - a[j][1]) * (a[i][1] - a[j][1])) + (a[i][2] - a[j][2]) * (a[i][2] - a[j][2]));
+                double dt = sqrt(((b[i][0] - b[j][0]) * (b[i][0] - b[j][0]) + (b[i][1] - b[j][1]) * (b[i][1] - b[j][1])) + (b[i][2] - b[j][2]) * (b[i][2] - b[j][2]));
+                if (ds < dt * cfg.similar_th || dt < ds * cfg.similar_th) edge_ok = false;
+            }
+        if (!edge_ok) { if (lane == 0) r_inl[slot] = -1; return; }
+    }
     double ma[3], mb[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -76,14 +91,6 @@ __global__ __launch_bounds__(256) void ransac_eval_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             t[i] = mb[i] - ((R[i * 3] * ma[0] + R[i * 3 + 1] * ma[1]) + R[i * 3 + 2] * ma[2]);
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = i + 1; j < 3; ++j) {
-                double ds = sqrt(((a[i][0] - a[j][0]) * (a[i][0] - a[j][0]) + (a[i][1] - a[j][1]) * (a[i][1] - a[j][1])) + (a[i][2] - a[j][2]) * (a[i][2] - a[j][2]));
-                double dt = sqrt(((b[i][0] - b[j][0]) * (b[i][0] - b[j][0]) + (b[i][1] - b[j][1]) * (b[i][1] - b[j][1])) + (b[i][2] - b[j][2]) * (b[i][2] - b[j][2]));
-                if (ds < dt * cfg.similar_th || dt < ds * cfg.similar_th) valid = false;
-            }
     }
     if (valid) {
 #pragma unroll
@@ -133,59 +140,165 @@ __global__ __launch_bounds__(256) void ransac_eval_kernel(const float* __restric
     }
 }
 
-__global__ void ransac_scan_kernel(const int32_t* __restrict__ C_dev, int max_C, RansacCfg cfg, int it0, PairState* st,
+// Open3D's sequential best-so-far / iteration-bound update over one batch, as two block-wide scans instead of one thread walking
+// 4096 slots (that walk was 0.5 ms per batch: 6.6 of the 7.4 ms RANSAC cost at confidence 1.0, where all 13 batches run).
+// The sequential rule, per slot in iteration order:   stop when itr >= max_iter or itr >= est_k;   a valid hypothesis becomes the
+// best if it has more inliers, or as many and a smaller rmse (ties keep the EARLIER one);   a new best sets
+// est_k = min(est_k, ceil(est_d(inliers)))  when confidence < 1  (`if (est_d < est_k) est_k = ceil(est_d)` is that minimum).
+//   scan 1: running best = inclusive scan with  combine(L, R) = better(R, L) ? R : L  (associative, left-biased), seeded with the
+//           best carried in from the previous batches;  slot i is a RECORD iff it beats the running best in front of it;
+//   scan 2: est_k in front of slot i = min(carried est_k, est of every record before i)  (a record's est only depends on its inliers);
+//   stop   = the first slot whose iteration number reaches max_iter or the est_k in front of it;  the result is the running state
+//           in front of slot `stop`.  Every value is computed by the same expressions as in the sequential loop.
+struct RBest { int inl; double rmse; int slot; };      // slot -1: the best carried in; inl -1: nothing valid
+__device__ __forceinline__ bool rbetter(const RBest& a, const RBest& b)   // a (valid) replaces b in the sequential loop
+{
+    return a.inl > b.inl || (a.inl == b.inl && a.rmse < b.rmse);
+}
+__device__ __forceinline__ int ransac_est(int inl, int C, double confidence)
+{
+    const double ratio = (double)inl / (double)C;
+    const double r3 = (ratio * ratio) * ratio;
+    double est_d;
+    if (r3 >= 1.0) est_d = 0.0;
+    else est_d = bxd_log(1.0 - confidence) / bxd_log(1.0 - r3);
+    return est_d < 2147483000.0 ? (int)ceil(est_d) : 0x7fffffff;      // est_k never exceeds max_iter: a huge est_d changes nothing
+}
+
+__global__ __launch_bounds__(1024) void ransac_scan_kernel(const int32_t* __restrict__ C_dev, int max_C, RansacCfg cfg, int it0, PairState* st,
                                    const int32_t* __restrict__ skip_flag, const int32_t* __restrict__ r_inl,
                                    const double* __restrict__ r_err, const double* __restrict__ r_T, int last,
                                    double* __restrict__ T_out, int32_t* __restrict__ info_out)
 {
-    // the batch's inlier counts and squared-error sums are staged in LDS by the whole workgroup (coalesced), then ONE thread
-    // replays Open3D's sequential best-so-far / iteration-bound update over them: a single thread reading 4096 slots straight from
-    // global memory cost ~0.3 ms per batch, i.e. 4 ms per pair at confidence 1.0 (all 50 000 iterations)
-    __shared__ int s_inl[BX_RANSAC_BATCH];
-    __shared__ double s_err[BX_RANSAC_BATCH];
+    constexpr int NT = 1024, PER = BX_RANSAC_BATCH / NT;       // 4 consecutive slots per thread
+    static_assert(BX_RANSAC_BATCH % NT == 0, "slots per thread");
+    __shared__ int s_inl[NT];
+    __shared__ double s_rmse[NT];
+    __shared__ int s_slot[NT];
+    __shared__ int s_est[NT];
+    __shared__ int s_stop;
     if (skip_flag && *skip_flag) return;
-    for (int i = threadIdx.x; i < BX_RANSAC_BATCH; i += blockDim.x) { s_inl[i] = r_inl[i]; s_err[i] = r_err[i]; }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
+    const int t = threadIdx.x;
     int C = *C_dev;
     C = C < max_C ? C : max_C;
-    int est_k = st->r_est_k < cfg.max_iter ? st->r_est_k : cfg.max_iter;
-    int best_inl = st->r_best_inl;
-    double best_rmse = st->r_best_rmse;
-    int itr = st->r_itr;
-    if (C >= 3 && cfg.dist_th > 0.0 && it0 < est_k && itr == it0) {
-        for (int slot = 0; slot < BX_RANSAC_BATCH; ++slot) {
-            itr = it0 + slot;
-            if (itr >= cfg.max_iter || itr >= est_k) break;
-            int inl = s_inl[slot];
-            if (inl >= 0) {
-                double rmse = inl > 0 ? sqrt(s_err[slot] / (double)inl) : 0.0;
-                if (inl > best_inl || (inl == best_inl && rmse < best_rmse)) {
-                    best_inl = inl; best_rmse = rmse;
-                    for (int i = 0; i < 12; ++i) st->T[i] = r_T[(size_t)slot * 12 + i];
-                    if (cfg.confidence < 1.0) {
-                        double ratio = (double)inl / (double)C;
-                        double r3 = (ratio * ratio) * ratio;
-                        double est_d;
-                        if (r3 >= 1.0) est_d = 0.0;
-                        else est_d = bxd_log(1.0 - cfg.confidence) / bxd_log(1.0 - r3);
-                        if (est_d < (double)est_k) est_k = (int)ceil(est_d);
-                    }
-                }
-            }
-            itr = it0 + slot + 1;
+    const int est_in = st->r_est_k < cfg.max_iter ? st->r_est_k : cfg.max_iter;
+    const RBest carry{st->r_best_inl, st->r_best_rmse, -1};
+    const int itr_in = st->r_itr;
+    const bool run = C >= 3 && cfg.dist_th > 0.0 && it0 < est_in && itr_in == it0;     // uniform
+    const bool shrink = cfg.confidence < 1.0;
+    if (!run) {
+        if (last && t == 0) {
+            st->num_inliers = carry.inl;
+            st->ransac_iters = itr_in;
+            if (T_out)
+                for (int i = 0; i < 16; ++i) T_out[i] = st->T[i];
+            if (info_out) { info_out[0] = carry.inl; info_out[1] = itr_in; }
         }
-        st->r_best_inl = best_inl;
-        st->r_best_rmse = best_rmse;
-        st->r_est_k = est_k;
-        st->r_itr = itr;
+        return;
     }
-    if (last) {
-        st->num_inliers = best_inl;
-        st->ransac_iters = st->r_itr;
-        if (T_out)
-            for (int i = 0; i < 16; ++i) T_out[i] = st->T[i];
-        if (info_out) { info_out[0] = best_inl; info_out[1] = st->r_itr; }
+    // ---- this thread's slots; leftmost best among the valid ones
+    RBest v[PER];
+    RBest loc{-1, 0.0, -2};
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int slot = t * PER + u;
+        const int inl = r_inl[slot];
+        v[u].inl = inl; v[u].slot = slot;
+        v[u].rmse = inl > 0 ? sqrt(r_err[slot] / (double)inl) : 0.0;
+        if (inl >= 0 && (loc.inl < 0 || rbetter(v[u], loc))) loc = v[u];
+    }
+    s_inl[t] = loc.inl; s_rmse[t] = loc.rmse; s_slot[t] = loc.slot;
+    __syncthreads();
+    // ---- scan 1 (inclusive, Hillis-Steele): an invalid element (inl -1) loses to everything and never replaces anything
+    for (int d = 1; d < NT; d <<= 1) {
+        RBest L{-1, 0.0, -2};
+        const bool take = t >= d;
+        if (take) L = RBest{s_inl[t - d], s_rmse[t - d], s_slot[t - d]};
+        __syncthreads();
+        if (take && L.inl >= 0) {
+            const RBest R{s_inl[t], s_rmse[t], s_slot[t]};
+            if (!(R.inl >= 0 && rbetter(R, L))) { s_inl[t] = L.inl; s_rmse[t] = L.rmse; s_slot[t] = L.slot; }     // left-biased
+        }
+        __syncthreads();
+    }
+    // running best in front of this thread's first slot
+    RBest before = carry;
+    if (t > 0) {
+        const RBest Pm{s_inl[t - 1], s_rmse[t - 1], s_slot[t - 1]};
+        if (Pm.inl >= 0 && rbetter(Pm, before)) before = Pm;
+    }
+    // ---- records among this thread's slots and their est_k
+    bool rec[PER];
+    int est[PER];
+    int est_loc = 0x7fffffff;
+    {
+        RBest cur = before;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            rec[u] = v[u].inl >= 0 && rbetter(v[u], cur);
+            est[u] = 0x7fffffff;
+            if (rec[u]) {
+                cur = v[u];
+                if (shrink) est[u] = ransac_est(v[u].inl, C, cfg.confidence);
+                est_loc = est[u] < est_loc ? est[u] : est_loc;
+            }
+        }
+    }
+    // ---- scan 2 (inclusive min)
+    s_est[t] = est_loc;
+    if (t == 0) s_stop = BX_RANSAC_BATCH;
+    __syncthreads();
+    for (int d = 1; d < NT; d <<= 1) {
+        int L = 0x7fffffff;
+        const bool take = t >= d;
+        if (take) L = s_est[t - d];
+        __syncthreads();
+        if (take && L < s_est[t]) s_est[t] = L;
+        __syncthreads();
+    }
+    int est_before = est_in;
+    if (t > 0 && s_est[t - 1] < est_before) est_before = s_est[t - 1];
+    // ---- stop: the first slot whose iteration number reaches max_iter or the est_k in front of it
+    {
+        int e = est_before, my_stop = BX_RANSAC_BATCH;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int slot = t * PER + u, itr = it0 + slot;
+            if (my_stop == BX_RANSAC_BATCH && (itr >= cfg.max_iter || itr >= e)) my_stop = slot;
+            if (rec[u] && est[u] < e) e = est[u];
+        }
+        if (my_stop < BX_RANSAC_BATCH) atomicMin(&s_stop, my_stop);
+    }
+    __syncthreads();
+    const int stop = s_stop;
+    // ---- state in front of slot `stop`: written by the thread that owns slot stop - 1 (thread 0 when stop == 0)
+    const int owner = stop > 0 ? (stop - 1) / PER : 0;
+    if (t == owner) {
+        RBest cur = before;
+        int e = est_before;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int slot = t * PER + u;
+            if (slot < stop && rec[u]) {
+                cur = v[u];
+                if (est[u] < e) e = est[u];
+            }
+        }
+        if (cur.slot >= 0)
+            for (int i = 0; i < 12; ++i) st->T[i] = r_T[(size_t)cur.slot * 12 + i];
+        st->r_best_inl = cur.inl;
+        st->r_best_rmse = cur.rmse;
+        st->r_est_k = e;
+        st->r_itr = it0 + stop;
+        if (last) {
+            st->num_inliers = cur.inl;
+            st->ransac_iters = it0 + stop;
+            if (T_out) {
+                for (int i = 0; i < 12; ++i) T_out[i] = cur.slot >= 0 ? r_T[(size_t)cur.slot * 12 + i] : st->T[i];
+                T_out[12] = 0.0; T_out[13] = 0.0; T_out[14] = 0.0; T_out[15] = 1.0;
+            }
+            if (info_out) { info_out[0] = cur.inl; info_out[1] = it0 + stop; }
+        }
     }
 }
 
@@ -299,7 +412,7 @@ int bxk_ransac(bx_ctx* c, hipStream_t s, const float* ss, const float* tt, const
         if (max_C >= 3 && cfg.max_iter > 0)
             hipLaunchKernelGGL(ransac_eval_kernel, dim3(BX_RANSAC_BATCH / 4), dim3(256), 0, s, ss, tt, corr, C_dev, max_C, cfg, it0,
                                c->state, skip_flag, c->ransac_inl, c->ransac_err, c->ransac_T);
-        hipLaunchKernelGGL(ransac_scan_kernel, dim3(1), dim3(256), 0, s, C_dev, max_C, cfg, it0, c->state, skip_flag, c->ransac_inl,
+        hipLaunchKernelGGL(ransac_scan_kernel, dim3(1), dim3(1024), 0, s, C_dev, max_C, cfg, it0, c->state, skip_flag, c->ransac_inl,
                            c->ransac_err, c->ransac_T, b == nb - 1 ? 1 : 0, T_out, info_out);
     }
     BX_LAUNCH_CHECK();
