@@ -60,8 +60,9 @@ def estimate_pose(ss, tt, inlier_ind, cfg, seed, call):
     return T, n, it
 
 
-def register_pair(src, tgt, pw, cfg, aligned, seed, cap=None):
-    """Returns (pose 4x4, num_inliers, num_mutual, num_inlier_ind, scales_used). pw = weights.fold_and_pack(sd)."""
+def register_pair(src, tgt, pw, cfg, aligned, seed, cap=None, perms=None):
+    """Returns (pose 4x4, num_inliers, num_mutual, num_inlier_ind, scales_used). pw = weights.fold_and_pack(sd).
+    perms = (perm_src [S][n_src], perm_tgt [S][n_tgt]) replaces the seed-derived permutations (a caller that drew them itself)."""
     src = np.ascontiguousarray(src, np.float32)
     tgt = np.ascontiguousarray(tgt, np.float32)
     K = cfg.patch.num_fps
@@ -87,8 +88,8 @@ def register_pair(src, tgt, pw, cfg, aligned, seed, cap=None):
         des_r = O.radius(pts, n_orig, bk, cfg.patch.search_radius_thresholds[i])
         if cap is not None:
             cap[f"s{i}_des_r"] = des_r
-        perm_s = O.make_perm(len(src), seed, 2 * i)
-        perm_t = O.make_perm(len(tgt), seed, 2 * i + 1)
+        perm_s = O.make_perm(len(src), seed, 2 * i) if perms is None else np.asarray(perms[0][i])
+        perm_t = O.make_perm(len(tgt), seed, 2 * i + 1) if perms is None else np.asarray(perms[1][i])
         s_desc, s_equi, s_R = desc_forward(src, src_kpts, des_r, aligned, perm_s, pw, cfg, cap, f"s{i}_src_")
         t_desc, t_equi, t_R = desc_forward(tgt, tgt_kpts, des_r, aligned, perm_t, pw, cfg, cap, f"s{i}_tgt_")
         s_mids, t_mids, _, _ = O.mutual(s_desc, t_desc)

@@ -65,6 +65,14 @@ def test_runner_matches_step_by_step(tmp_path, bx, packed):
             res = ctx.register_pair(src, tgt, cfg.patch.is_aligned_to_global_z, np.stack(ps), np.stack(pt), seed)
             pose = np.array(res.pose, np.float64).reshape(4, 4).astype(np.float32)
             assert np.array_equal(pose, poses[i]), i
+            if i == 0:
+                # ... and the pipeline is not only consistent with itself: the registration of the first pair, on the clouds the GPU
+                # pre-processing produced and with the permutations / seed the loop drew, equals the CPU oracle's bit for bit
+                from oracle import pipeline as PL
+                ref = PL.register_pair(src.cpu().numpy(), tgt.cpu().numpy(), packed, cfg, cfg.patch.is_aligned_to_global_z, seed,
+                                       perms=(np.stack(ps), np.stack(pt)))
+                assert (res.num_inliers, res.num_mutual, res.num_inlier_ind, res.scales_used) == tuple(ref[1:])
+                assert np.array_equal(np.array(res.pose, np.float64).reshape(4, 4), np.asarray(ref[0], np.float64))
             assert rows[i, 4] == res.num_inliers and rows[i, 5] == res.num_mutual and rows[i, 7] == res.scales_used
             assert rows[i, 2] == evaluate.compute_rte(pose, np.asarray(p["relt_pose"], np.float32))      # float32 ground truth like the reference collate
             assert np.array_equal(evaluate.state_pose(rows[i]), pose)
