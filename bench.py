@@ -10,7 +10,7 @@ means something.  A "step" is one pair through bx_register_pair on every rank (w
 `steps` pairs; pairs are independent, the only collective is one all-gather of 192-byte float64 result records).
 Inputs are resident in HBM before the timed region.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--inflight C] [--workload 3dmatch|3dmatch-noisy|kitti|tiers]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--inflight C] [--workload 3dmatch|3dlomatch|3dmatch-noisy|kitti|tiers]
   N > 1: either  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
          or      python bench.py --gpus N   (no WORLD_SIZE in the environment: bench.py spawns its own N ranks)
 
@@ -42,6 +42,8 @@ WORKLOADS = {
                            "%d scales, %d FPS keypoints, %d pts/patch, RANSAC+refine, N~U[20k,60k] pts/cloud (BASELINE configs[1])"),
     "3dmatch-noisy": ("3DMatch", "3DMatch-like synthetic pairs (independently sampled, jittered fragments: random weights cannot "
                                  "register these), %d scales, %d FPS keypoints, %d pts/patch, RANSAC+refine, N~U[20k,60k] (round-1 workload)"),
+    "3dlomatch": ("3DLoMatch", "3DLoMatch-like synthetic pairs (as 3dmatch, overlap 10-30 %%), %d scales, %d FPS keypoints, %d pts/patch, "
+                               "RANSAC+refine, N~U[20k,60k] pts/cloud (the low-overlap half of BASELINE configs[3])"),
     "kitti": ("KITTI", "KITTI-like synthetic outdoor pairs (two LiDAR sweeps, aligned z, confidence 1.0 = 50k RANSAC iterations, no "
                        "refinement), %d scales, %d FPS keypoints, %d pts/patch (BASELINE configs[2] geometry)"),
     "tiers": ("TIERS_hetero", "TIERS_hetero-like pairs (dense 128-ring sweep of ~100k points vs its 64-ring subset of ~50k points re-posed, "
@@ -66,6 +68,10 @@ def make_pair(bx, workload, seed):
     if workload == "3dmatch":
         n = int(np.random.default_rng(1000 + seed).integers(20000, 60001))
         return bx.synth.make_pair(seed, "indoor", n_target=n, shared=True)
+    if workload == "3dlomatch":
+        rng = np.random.default_rng(2000 + seed)
+        n = int(rng.integers(20000, 60001))
+        return bx.synth.make_pair(seed, "indoor", n_target=n, shared=True, overlap=float(rng.uniform(0.1, 0.3)))
     if workload == "3dmatch-noisy":
         n = int(np.random.default_rng(1000 + seed).integers(20000, 60001))
         return bx.synth.make_pair(seed, "indoor", n_target=n)
@@ -122,6 +128,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs (cycled; the same list on every rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--num-fps", type=int, default=5000)
+    ap.add_argument("--latency-tiles", type=int, default=2, help="keypoint tiles of the latency-form measurement (0/1 = skip it)")
     ap.add_argument("--ppp", type=int, default=1024)
     ap.add_argument("--scales", type=int, default=3)
     ap.add_argument("--workload", choices=list(WORKLOADS), default="3dmatch",
@@ -181,7 +188,7 @@ def main():
         cx.attach_lane(lane)
     results = [ctxs[i].new_result() for i in range(C)]
 
-    def run(n_steps, depth=C):
+    def run(n_steps, depth=C, ctxs=ctxs):
         """Round-robin the pairs over `depth` contexts; each context's stream serialises its own pairs.  Global pair id of step s on
         rank r = r + world * s; it selects the synthetic pair (id mod distinct), so any world size processes the same pair list."""
         lat, recs, evs = [], [], []
@@ -239,7 +246,20 @@ def main():
     if rank == 0 and args.dump_records:
         np.save(args.dump_records, allrec)
     # Latency at ONE pair in flight (service time of a pair; p50_ms_per_pair above is queueing latency at `inflight` pairs in flight)
-    lat1, _ = run(min(len(dpairs) * 2, 8), depth=1)
+    n1 = min(len(dpairs) * 2, 8)
+    lat1, rec1 = run(n1, depth=1)
+    # the same in the LATENCY FORM of the whole-pair call (bx_params.keypoint_tiles): FPS on the context's own stream in tiles,
+    # the descriptors of a tile computed while the next one is sampled.  Same results bit for bit (checked here).
+    lat1t, tiles_same = None, None
+    if args.latency_tiles > 1:
+        import copy
+        cfg_t = copy.deepcopy(cfg)
+        cfg_t.test.keypoint_tiles = args.latency_tiles
+        ctx_t = lib.Context(cfg_t, max_points=max(60000, max(max(len(p['src']), len(p['tgt'])) for p in pairs)), device=local, packed_weights=pw)
+        run(2, depth=1, ctxs=[ctx_t])
+        lat1t, rec1t = run(n1, depth=1, ctxs=[ctx_t])
+        tiles_same = bool(all(np.array_equal(a[:22], b[:22]) for a, b in zip(rec1, rec1t)))
+        ctx_t.close()
     # Kernel-quality pass: the same workload, ONE pair in flight, hipEvents around every stage on the kernels' own
     # stream (bx_profile_*).  Kept out of the throughput region because with several pairs in flight a kernel's
     # event-to-event time includes the other pairs' kernels it shares the GPU with.
@@ -335,6 +355,11 @@ def main():
             "value": round(value, 4), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "p50_ms_per_pair": round(float(np.median(lat)), 3),
             "p50_ms_per_pair_inflight1": round(float(np.median(lat1)), 3),
+            "p50_ms_per_pair_latency_form": None if lat1t is None else {
+                "p50_ms": round(float(np.median(lat1t)), 3), "keypoint_tiles": args.latency_tiles, "pairs_in_flight": 1,
+                "results_identical_to_throughput_form": tiles_same,
+                "note": "bx_params.keypoint_tiles: furthest point sampling on the context's own stream in tiles, descriptor work of a tile "
+                        "beside the sampling of the next"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl_text % (S, K, P),
                        "pairs_in_flight_per_gpu": C, "parallelism": "pair-sharded x%d, one all-gather of %d B float64 records" % (world, 8 * D.RECORD),

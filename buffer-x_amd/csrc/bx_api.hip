@@ -93,6 +93,18 @@ void carve(bx_ctx* c, char* base, size_t* total)
         c->Rpatch[i] = cv.take<float>(K * 9);
         c->nn_key[i] = cv.take<unsigned long long>(K);
     }
+    const bool tiled = c->p.keypoint_tiles > 1;
+    for (size_t sc = 0; sc < (size_t)BX_MAX_SCALES; ++sc)
+        for (int i = 0; i < 2; ++i) {
+            const bool own = tiled && sc > 0 && sc < S;     // scale 0 uses the shared arrays
+            c->desc_sc[sc][i] = own ? cv.take<float>(K * 32) : c->desc_out[i];
+            c->equi_sc[sc][i] = own ? cv.take<float>(K * BX_EA * 32) : c->equi[i];
+            c->R_sc[sc][i] = own ? cv.take<float>(K * 9) : c->Rpatch[i];
+        }
+    for (int i = 0; i < 2; ++i) c->fps_td[i] = tiled ? cv.take<float>(NMAX) : nullptr;
+    c->patches2 = tiled ? cv.take<float>(K * P * 3) : nullptr;
+    c->feat2 = tiled ? cv.take<float>(K * BX_RAD * BX_EA * 16) : nullptr;
+    for (int i = 0; i < 2; ++i) c->act2[i] = tiled ? cv.take<float>(K * 8 * BX_EA * 16) : nullptr;   // largest Cylindrical_Net map: 128 channels
     c->s_mids = cv.take<int32_t>(K);
     c->t_mids = cv.take<int32_t>(K);
     c->ind = cv.take<float>(K);
@@ -290,10 +302,10 @@ int check_ctx(bx_ctx* c, bool need_weights)
     return BX_OK;
 }
 
-int desc_stack(bx_ctx* c, hipStream_t s, const float* feat, int K, float* desc, float* equi, float* x_out)
+int desc_stack(bx_ctx* c, hipStream_t s, const float* feat, int K, float* desc, float* equi, float* x_out, int scratch = 0)
 {
     const float* in = feat;
-    float* bufs[2] = {c->act0, c->act1};
+    float* bufs[2] = {scratch ? c->act2[0] : c->act0, scratch ? c->act2[1] : c->act1};
     int rc;
     for (int l = 0; l < BX_NDESC; ++l) {
         float* out = bufs[l & 1];
@@ -372,6 +384,16 @@ static int create_impl(bx_ctx* c, int device_id)
         thr[m] = (float)(r * r);
     }
     if ((rc = upload(&c->d_rad_thr, thr.data(), thr.size())) != BX_OK) return rc;
+    if (p.keypoint_tiles > 1) {
+        int lo = 0, hi = 0;
+        BX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));      // hi = numerically lowest = most urgent
+        BX_HIP(hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, hi));
+        BX_HIP(hipStreamCreateWithFlags(&c->tgt_stream, hipStreamNonBlocking));
+        BX_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        BX_HIP(hipEventCreateWithFlags(&c->ev_tgt_go, hipEventDisableTiming));
+        BX_HIP(hipEventCreateWithFlags(&c->ev_tgt_done, hipEventDisableTiming));
+        for (int i = 0; i < BX_MAX_TILES; ++i) BX_HIP(hipEventCreateWithFlags(&c->ev_tile[i], hipEventDisableTiming));
+    }
     if (p.pose_estimator == 1) {
         if (!(p.kiss_resolution > 0.0)) { bx_set_error("bx_create: kiss_resolution must be positive"); return BX_ERR_ARG; }
         c->kiss_max_C = p.num_fps * p.num_scales;
@@ -391,7 +413,8 @@ int bx_create(int device_id, const bx_params* params, bx_ctx** out)
         return BX_ERR_ARG;
     }
     if (p.num_fps < 1 || p.num_points_per_patch < 2 || p.num_scales < 1 || p.num_scales > BX_MAX_SCALES || p.max_points < 1 ||
-        p.num_points_radius_estimate < 1 || p.voxel_sample < 1 || p.voxel_sample > 16) {
+        p.num_points_radius_estimate < 1 || p.voxel_sample < 1 || p.voxel_sample > 16 || p.keypoint_tiles < 0 ||
+        p.keypoint_tiles > BX_MAX_TILES) {
         bx_set_error("bx_create: invalid parameters");
         return BX_ERR_ARG;
     }
@@ -429,6 +452,12 @@ int bx_destroy(bx_ctx* c)
         for (auto& e : *v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         delete v;
     }
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    if (c->tgt_stream) (void)hipStreamDestroy(c->tgt_stream);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_tgt_go) (void)hipEventDestroy(c->ev_tgt_go);
+    if (c->ev_tgt_done) (void)hipEventDestroy(c->ev_tgt_done);
+    for (int i = 0; i < BX_MAX_TILES; ++i) if (c->ev_tile[i]) (void)hipEventDestroy(c->ev_tile[i]);
     (void)hipFree(c->arena);
     (void)hipFree(c->kiss_ws);
     (void)hipFree(c->d_centres); (void)hipFree(c->d_rot); (void)hipFree(c->d_rowc); (void)hipFree(c->d_rad_thr);
@@ -773,11 +802,36 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
     c->skip = nullptr;
     hipLaunchKernelGGL(state_reset_kernel, dim3(1), dim3(64), 0, s, st, c->err_flag);
 
-    // (1) keypoints: ONE furthest-point sampling per cloud; FPS(nk) is a prefix of FPS(K)
+    // (1) keypoints: ONE furthest-point sampling per cloud; FPS(nk) is a prefix of FPS(K).
+    // Latency form (params.keypoint_tiles > 1): the run is cut into tiles of keypoints on the context's own stream; tile 0 ends
+    // where the radius estimation has its keypoints, and the descriptor work of a tile runs on the caller's stream while the next
+    // tile is still being sampled (a descriptor depends on its own keypoint only).
     const float* clouds[2] = {src, tgt};
     const int ns[2] = {n_src, n_tgt};
     const int32_t* perms[2] = {perm_src, perm_tgt};
-    { ProfScope ps(c, s, 0); if ((rc = bxk_fps(c, s, clouds, ns, 2, KM, c->fps_idx, c->kpts)) != BX_OK) return rc; }
+    int tb[BX_MAX_TILES + 1] = {0};
+    int T = 1;
+    if (p.keypoint_tiles > 1 && K > NK + 4) {
+        const int first = (NK + 3) & ~3;
+        tb[1] = first;
+        for (int t = 2; t <= p.keypoint_tiles; ++t) {
+            int e = t == p.keypoint_tiles ? K : first + (int)((int64_t)(K - first) * (t - 1) / (p.keypoint_tiles - 1)) / 4 * 4;
+            if (e > tb[T]) tb[++T] = e;
+        }
+    }
+    if (T == 1) tb[1] = KM;
+    const bool tiled = T > 1;
+    if (tiled && c->cap_on) { bx_set_error("bx_register_pair: bx_set_capture needs keypoint_tiles <= 1"); return BX_ERR_STATE; }
+    hipStream_t fs = tiled ? c->aux_stream : s;
+    if (tiled) {
+        BX_HIP(hipEventRecord(c->ev_fork, s));
+        BX_HIP(hipStreamWaitEvent(fs, c->ev_fork, 0));
+    }
+    for (int t = 0; t < T; ++t) {
+        { ProfScope ps(c, fs, 0); if ((rc = bxk_fps_range(c, fs, clouds, ns, 2, tb[t], tb[t + 1], KM, c->fps_idx, c->kpts)) != BX_OK) return rc; }
+        if (tiled) BX_HIP(hipEventRecord(c->ev_tile[t], fs));
+    }
+    if (tiled) BX_HIP(hipStreamWaitEvent(s, c->ev_tile[0], 0));
 
     LaneScope lane_main(c, s, 1);
     // (2) radius estimation histogram: the LARGER cloud and its keypoints (models/BUFFERX.py:654-665), once per pair
@@ -791,42 +845,94 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
     }
     { ProfScope ps(c, s, 1); if ((rc = bxk_radius_hist(c, s, rpts, rn, c->kpts[big], NK)) != BX_OK) return rc; }
 
-    // every scale's radius up front (the bisections share the histogram: one launch), then the grids + candidate row tables of
-    // all 2 x S (cloud, scale) sets in one batch of six launches; the per-scale permutation is applied on the fly
+    // every scale's radius up front (the bisections share the histogram: one launch), then the grids of all 2 x S (cloud, scale)
+    // sets in one batch of six launches; the per-scale permutation is applied on the fly
     { ProfScope ps(c, s, 1); if ((rc = bxk_radius_bisect_all(c, s, (int64_t)ns[big], NK, p.search_radius_thresholds, S, st->des_r)) != BX_OK) return rc; }
-    { ProfScope ps(c, s, 13); if ((rc = bxk_ball_prepare(c, s, clouds, ns, perms, c->kpts, 2, K, st->des_r, S, p.search_radius_thresholds)) != BX_OK) return rc; }
+    { ProfScope ps(c, s, 13); if ((rc = bxk_ball_grids(c, s, clouds, ns, perms, 2, st->des_r, S, p.search_radius_thresholds)) != BX_OK) return rc; }
 
     const bool early = p.enable_early_exit != 0;
+    // descriptors of keypoints [k0, k0 + kn) of one (scale, cloud): neighbour gather -> patch features -> Cylindrical_Net
+    // Latency form: the target cloud's chain runs on the context's second stream with its own scratch, so that the tail of one
+    // chain's launch is filled by the other's (the same overlap several pairs in flight give the throughput form).
+    auto describe = [&](int i, int cl, int k0, int kn) -> int {
+        const bool capc = c->cap_on && c->cap.scale == i && c->cap.cloud == cl;
+        const bool side = tiled && cl == 1;
+        hipStream_t ds = side ? c->tgt_stream : s;
+        float* patches = side ? c->patches2 : c->patches;
+        float* feat = side ? c->feat2 : c->feat;
+        // expected neighbourhood = threshold % of the cloud: large ones get 4 waves per keypoint, small ones 2 (measured)
+        c->ball_waves_hint = p.search_radius_thresholds[i] >= 1.5 ? 4 : 2;
+        // the whole-pair path does not need the ball_query index list (nothing downstream reads it): idx_out = nullptr
+        { ProfScope ps(c, ds, 2); if ((rc = bxk_ball_query(c, ds, cl * S + i, ns[cl], c->kpts[cl], k0, kn, &st->des_r[i], P, nullptr, patches)) != BX_OK) return rc; }
+        if (capc && c->cap.pts_perm) {      // the permuted cloud is never materialised on the hot path
+            if ((rc = bx_permute_launch(ds, clouds[cl], perms[cl] + (size_t)i * ns[cl], ns[cl], c->pts_perm, nullptr)) != BX_OK) return rc;
+        }
+        { ProfScope ps(c, ds, 3); if ((rc = bxk_patch_features(c, ds, patches, kn, P, &st->des_r[i], aligned_z, c->R_sc[i][cl] + (size_t)k0 * 9, feat)) != BX_OK) return rc; }
+        if (capc) {
+            if ((rc = cap_copy(ds, c->cap.pts_perm, c->pts_perm, (size_t)ns[cl] * 3)) != BX_OK) return rc;
+            if ((rc = cap_copy(ds, c->cap.patches, patches, (size_t)K * P * 3)) != BX_OK) return rc;
+            if ((rc = cap_copy(ds, c->cap.feat, feat, (size_t)K * BX_RAD * BX_EA * 16)) != BX_OK) return rc;
+        }
+        if (side) {
+            ProfScope ps(c, ds, 4);
+            if ((rc = desc_stack(c, ds, feat, kn, c->desc_sc[i][cl] + (size_t)k0 * 32, c->equi_sc[i][cl] + (size_t)k0 * BX_EA * 32, nullptr, 1)) != BX_OK) return rc;
+        } else {
+            LaneScope ls(c, ds, 2); ProfScope ps(c, ds, 4);
+            if ((rc = desc_stack(c, ds, feat, kn, c->desc_sc[i][cl] + (size_t)k0 * 32, c->equi_sc[i][cl] + (size_t)k0 * BX_EA * 32, capc ? c->cap.x : nullptr)) != BX_OK) return rc;
+        }
+        return BX_OK;
+    };
+    // the target chain starts behind whatever the caller's stream has enqueued so far / the caller's stream waits for it
+    auto tgt_go = [&]() -> int {
+        if (!tiled) return BX_OK;
+        BX_HIP(hipEventRecord(c->ev_tgt_go, s));
+        BX_HIP(hipStreamWaitEvent(c->tgt_stream, c->ev_tgt_go, 0));
+        return BX_OK;
+    };
+    auto tgt_join = [&]() -> int {
+        if (!tiled) return BX_OK;
+        BX_HIP(hipEventRecord(c->ev_tgt_done, c->tgt_stream));
+        BX_HIP(hipStreamWaitEvent(s, c->ev_tgt_done, 0));
+        return BX_OK;
+    };
+    // tile by tile: candidate tables of the tile (all sets, one launch), then its descriptors -- of every scale when no early exit
+    // can skip the later ones, else of scale 0 only (the later scales then run over all keypoints behind the exit test)
+    c->skip = nullptr;
+    for (int t = 0; t < T; ++t) {
+        const int k0 = tb[t], kn = (t == T - 1 ? K : tb[t + 1]) - k0;
+        if (tiled && t > 0) BX_HIP(hipStreamWaitEvent(s, c->ev_tile[t], 0));
+        { ProfScope ps(c, s, 13); if ((rc = bxk_ball_rows(c, s, c->kpts, 2, S, k0, kn)) != BX_OK) return rc; }
+        if (!tiled) break;
+        if ((rc = tgt_go()) != BX_OK) return rc;
+        for (int i = 0; i < (early ? 1 : S); ++i)
+            for (int cl = 0; cl < 2; ++cl)
+                if ((rc = describe(i, cl, k0, kn)) != BX_OK) return rc;
+    }
+    if ((rc = tgt_join()) != BX_OK) return rc;
     int ransac_calls = 0;
     for (int i = 0; i < S; ++i) {
         c->skip = (early && i > 0) ? &st->done : nullptr;
         const bool capi = c->cap_on && c->cap.scale == i;
-        for (int cl = 0; cl < 2; ++cl) {
-            const bool capc = capi && c->cap.cloud == cl;
-            // expected neighbourhood = threshold % of the cloud: large ones get 4 waves per keypoint, small ones 2 (measured)
-            c->ball_waves_hint = p.search_radius_thresholds[i] >= 1.5 ? 4 : 2;
-            // the whole-pair path does not need the ball_query index list (nothing downstream reads it): idx_out = nullptr
-            { ProfScope ps(c, s, 2); if ((rc = bxk_ball_query(c, s, cl * S + i, ns[cl], c->kpts[cl], K, &st->des_r[i], P, nullptr, c->patches)) != BX_OK) return rc; }
-            if (capc && c->cap.pts_perm) {      // the permuted cloud is never materialised on the hot path
-                if ((rc = bx_permute_launch(s, clouds[cl], perms[cl] + (size_t)i * ns[cl], ns[cl], c->pts_perm, nullptr)) != BX_OK) return rc;
-            }
-            { ProfScope ps(c, s, 3); if ((rc = bxk_patch_features(c, s, c->patches, K, P, &st->des_r[i], aligned_z, c->Rpatch[cl], c->feat)) != BX_OK) return rc; }
-            if (capc) {
-                if ((rc = cap_copy(s, c->cap.pts_perm, c->pts_perm, (size_t)ns[cl] * 3)) != BX_OK) return rc;
-                if ((rc = cap_copy(s, c->cap.patches, c->patches, (size_t)K * P * 3)) != BX_OK) return rc;
-                if ((rc = cap_copy(s, c->cap.feat, c->feat, (size_t)K * BX_RAD * BX_EA * 16)) != BX_OK) return rc;
-            }
-            { LaneScope ls(c, s, 2); ProfScope ps(c, s, 4); if ((rc = desc_stack(c, s, c->feat, K, c->desc_out[cl], c->equi[cl], capc ? c->cap.x : nullptr)) != BX_OK) return rc; }
-            if (capi) {
+        if (!tiled || (early && i > 0)) {
+            if ((rc = tgt_go()) != BX_OK) return rc;
+            for (int cl = 0; cl < 2; ++cl)
+                if ((rc = describe(i, cl, 0, K)) != BX_OK) return rc;
+            if ((rc = tgt_join()) != BX_OK) return rc;
+        }
+        float* const* dsc = c->desc_sc[i];
+        float* const* eqv = c->equi_sc[i];
+        float* const* Rp = c->R_sc[i];
+        if (capi) {
+            for (int cl = 0; cl < 2; ++cl) {
                 if ((rc = cap_copy(s, c->cap.kpts[cl], c->kpts[cl], (size_t)K * 3)) != BX_OK) return rc;
-                if ((rc = cap_copy(s, c->cap.desc[cl], c->desc_out[cl], (size_t)K * 32)) != BX_OK) return rc;
-                if ((rc = cap_copy(s, c->cap.equi[cl], c->equi[cl], (size_t)K * BX_EA * 32)) != BX_OK) return rc;
-                if ((rc = cap_copy(s, c->cap.R[cl], c->Rpatch[cl], (size_t)K * 9)) != BX_OK) return rc;
+                if ((rc = cap_copy(s, c->cap.desc[cl], dsc[cl], (size_t)K * 32)) != BX_OK) return rc;
+                if ((rc = cap_copy(s, c->cap.equi[cl], eqv[cl], (size_t)K * BX_EA * 32)) != BX_OK) return rc;
+                if ((rc = cap_copy(s, c->cap.R[cl], Rp[cl], (size_t)K * 9)) != BX_OK) return rc;
             }
         }
-        { ProfScope ps(c, s, 6); if ((rc = bxk_mutual(c, s, c->desc_out[0], K, c->desc_out[1], K, c->s_mids, c->t_mids, &st->m_scale)) != BX_OK) return rc; }
-        { LaneScope ls(c, s, 2); ProfScope ps(c, s, 7); if ((rc = pose_stack(c, s, c->equi[0], c->equi[1], c->s_mids, c->t_mids, &st->m_scale, K, c->ind, nullptr)) != BX_OK) return rc; }
-        if ((rc = bxk_hypotheses(s, c->ind, c->s_mids, c->t_mids, &st->m_scale, K, c->Rpatch[0], c->Rpatch[1], c->kpts[0], c->kpts[1],
+        { ProfScope ps(c, s, 6); if ((rc = bxk_mutual(c, s, dsc[0], K, dsc[1], K, c->s_mids, c->t_mids, &st->m_scale)) != BX_OK) return rc; }
+        { LaneScope ls(c, s, 2); ProfScope ps(c, s, 7); if ((rc = pose_stack(c, s, eqv[0], eqv[1], c->s_mids, c->t_mids, &st->m_scale, K, c->ind, nullptr)) != BX_OK) return rc; }
+        if ((rc = bxk_hypotheses(s, c->ind, c->s_mids, c->t_mids, &st->m_scale, K, Rp[0], Rp[1], c->kpts[0], c->kpts[1],
                                  c->R_cat, c->t_cat, c->ss_cat, c->tt_cat, &st->M, c->skip)) != BX_OK) return rc;
         hipLaunchKernelGGL(accumulate_kernel, dim3(1), dim3(64), 0, s, st, i, c->skip);
         { ProfScope ps(c, s, 8); if ((rc = bxk_consensus(c, s, c->R_cat, c->t_cat, c->ss_cat, c->tt_cat, &st->M, (i + 1) * K, c->inlier_ind, &st->C, &st->best)) != BX_OK) return rc; }

@@ -125,6 +125,14 @@ struct bx_ctx {
     float* desc_out[2];                 // [K][32]
     float* equi[2];                     // [K][140][32]
     float* Rpatch[2];                   // [K][9]
+    // per-scale views of the three arrays above: all scales share one buffer unless the keypoint tiles of the latency mode are on
+    // (params.keypoint_tiles > 1: the descriptors of every scale are then produced tile by tile before any scale is matched)
+    float *desc_sc[BX_MAX_SCALES][2], *equi_sc[BX_MAX_SCALES][2], *R_sc[BX_MAX_SCALES][2];
+    float* fps_td[2];                   // [max_points] running min-distances between the launches of a tiled FPS run (else null)
+    hipStream_t aux_stream;             // latency mode: the FPS launches run here, beside the descriptor work of the caller's stream
+    hipStream_t tgt_stream;             // latency mode: the target cloud's descriptor chain (the source cloud's stays on the caller's)
+    hipEvent_t ev_fork, ev_tile[BX_MAX_TILES], ev_tgt_go, ev_tgt_done;
+    float *patches2, *feat2, *act2[2];  // latency mode: scratch of the target cloud's chain
     unsigned long long* nn_key[2];      // [K]
     int32_t *s_mids, *t_mids;           // [K]
     float* ind;                         // [K]
@@ -180,6 +188,8 @@ constexpr int BX_RANSAC_BATCH = 4096;
 // ------------------------------------------------------------------ kernel launchers (one per .hip file)
 int bxk_fps(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* n, int nclouds, int m, int32_t* const* idx_out,
             float* const* kpts_out);
+int bxk_fps_range(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* n, int nclouds, int j0, int j1, int m,
+                  int32_t* const* idx_out, float* const* kpts_out);
 int bxk_gather_rows(hipStream_t s, const float* pts, const int32_t* idx, int n, float* out);
 int bxk_radius_hist(bx_ctx* c, hipStream_t s, const float* pts, int n_pts, const float* kpts, int nk);
 int bxk_radius_bisect(bx_ctx* c, hipStream_t s, int64_t n_orig, int nk, double threshold, double* des_r_out);
@@ -187,7 +197,10 @@ int bxk_ball_group(bx_ctx* c, hipStream_t s, const float* pts_perm, int n, const
                    int P, int32_t* idx_out, float* patches_out);
 int bxk_ball_prepare(bx_ctx* c, hipStream_t s, const float* const* clouds, const int* ns, const int32_t* const* perms,
                      const float* const* kpts, int nclouds, int K, const double* radius, int S, const double* pw_hint);
-int bxk_ball_query(bx_ctx* c, hipStream_t s, int set, int n, const float* kpts, int K, const double* radius, int P,
+int bxk_ball_grids(bx_ctx* c, hipStream_t s, const float* const* clouds, const int* ns, const int32_t* const* perms, int nclouds,
+                   const double* radius, int S, const double* pw_hint);
+int bxk_ball_rows(bx_ctx* c, hipStream_t s, const float* const* kpts, int nclouds, int S, int k0, int K);
+int bxk_ball_query(bx_ctx* c, hipStream_t s, int set, int n, const float* kpts, int k0, int K, const double* radius, int P,
                    int32_t* idx_out, float* patches_out);
 int bxk_radius_bisect_all(bx_ctx* c, hipStream_t s, int64_t n_orig, int nk, const double* thresholds_host, int nthr, double* des_r_out);
 int bxk_patch_features(bx_ctx* c, hipStream_t s, const float* patches, int K, int P, const double* radius, int aligned,

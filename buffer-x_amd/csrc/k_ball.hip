@@ -602,7 +602,7 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
 }
 
 template <int LOGC, int QW>
-int launch_query_w(bx_ctx* c, hipStream_t s, int set, int K, const float* kpts, const double* radius, int P, int32_t* idx_out, float* patches_out)
+int launch_query_w(bx_ctx* c, hipStream_t s, int set, int k0, int K, const float* kpts, const double* radius, int P, int32_t* idx_out, float* patches_out)
 {
     const size_t lds = ((size_t)64 << LOGC) * 12 + (((size_t)P * 4 + 7) & ~(size_t)7) + (size_t)NPMAX * 8;   // bitmap | per-word prefix | ordered index list | pieces
     if (lds > 160 * 1024) { bx_set_error("bxk_ball_group: P=%d needs %zu B of LDS per keypoint (> 160 KiB)", P, lds); return BX_ERR_ARG; }
@@ -612,15 +612,15 @@ int launch_query_w(bx_ctx* c, hipStream_t s, int set, int K, const float* kpts, 
     }
     const size_t j = (size_t)set;
     hipLaunchKernelGGL((ball_query_kernel<LOGC, QW>), dim3(K), dim3(64 * QW), lds, s, c->ball_sorted + j * c->ball_st_pts,
-                       c->ball_start + j * c->ball_st_cnt, c->ball_grid + j, c->ball_ptab + j * c->ball_st_tab,
-                       c->ball_pnum + j * c->ball_st_num, c->ball_logpw[set], c->ball_pts4 + j * c->ball_st_pts, kpts, K,
+                       c->ball_start + j * c->ball_st_cnt, c->ball_grid + j, c->ball_ptab + j * c->ball_st_tab + (size_t)k0 * NPMAX,
+                       c->ball_pnum + j * c->ball_st_num + k0, c->ball_logpw[set], c->ball_pts4 + j * c->ball_st_pts, kpts, K,
                        radius, P, idx_out, patches_out, c->skip, getenv("BX_BALL_DEBUG") ? c->ball_dbg : nullptr);
     BX_LAUNCH_CHECK();
     return BX_OK;
 }
 
 template <int LOGC>
-int launch_query(bx_ctx* c, hipStream_t s, int set, int K, const float* kpts, const double* radius, int P, int32_t* idx_out, float* patches_out)
+int launch_query(bx_ctx* c, hipStream_t s, int set, int k0, int K, const float* kpts, const double* radius, int P, int32_t* idx_out, float* patches_out)
 {
     // waves per keypoint: 4 for the large neighbourhoods (their candidate scan dominates), 1 for the small ones (the
     // per-keypoint chain of dependent memory round trips dominates and more independent workgroups hide it better)
@@ -629,9 +629,9 @@ int launch_query(bx_ctx* c, hipStream_t s, int set, int K, const float* kpts, co
     // measured (K = 5000, P = 1024): 4 waves win whenever the bitmap sweep is long (n > 32768: LOGC >= 4) or the neighbourhood is
     // large (hint from the radius threshold); 2 waves only for small neighbourhoods in small clouds
     const int w = forced ? forced : (LOGC >= 4 ? 4 : c->ball_waves_hint);
-    if (w >= 4) return launch_query_w<LOGC, 4>(c, s, set, K, kpts, radius, P, idx_out, patches_out);
-    if (w == 1) return launch_query_w<LOGC, 1>(c, s, set, K, kpts, radius, P, idx_out, patches_out);
-    return launch_query_w<LOGC, 2>(c, s, set, K, kpts, radius, P, idx_out, patches_out);
+    if (w >= 4) return launch_query_w<LOGC, 4>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out);
+    if (w == 1) return launch_query_w<LOGC, 1>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out);
+    return launch_query_w<LOGC, 2>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out);
 }
 }  // namespace
 
@@ -670,35 +670,41 @@ int ball_logc(int n)
 }
 }  // namespace
 
-// Grids + row tables of `nclouds` clouds x S scales in six launches (see BallBatch).  clouds / perms / kpts: per cloud; perm[cl] is
-// [S][n] or nullptr (identity).  radius: device array of S doubles.
-int bxk_ball_prepare(bx_ctx* c, hipStream_t s, const float* const* clouds, const int* ns, const int32_t* const* perms,
-                     const float* const* kpts, int nclouds, int K, const double* radius, int S, const double* pw_hint)
+namespace {
+// the per-set array bases and strides of the context
+void batch_from_ctx(const bx_ctx* c, BallBatch& B)
 {
-    if (K <= 0) return BX_OK;
+    memset(&B, 0, sizeof(B));
+    B.bbox_part = c->ball_bbox_part; B.grid = c->ball_grid; B.cnt = c->ball_cnt; B.start = c->ball_start; B.bsum = c->ball_bsum;
+    B.cellrank = c->ball_cellrank; B.pts4 = c->ball_pts4; B.sorted = c->ball_sorted; B.ptab = c->ball_ptab; B.pnum = c->ball_pnum;
+    B.st_cnt = c->ball_st_cnt; B.st_bsum = c->ball_st_bsum; B.st_pts = c->ball_st_pts; B.st_tab = c->ball_st_tab; B.st_num = c->ball_st_num;
+}
+}  // namespace
+
+// Cell grids of `nclouds` clouds x S scales in six launches (see BallBatch).  clouds / perms: per cloud; perm[cl] is [S][n] or
+// nullptr (identity).  radius: device array of S doubles.  Independent of the keypoints.
+int bxk_ball_grids(bx_ctx* c, hipStream_t s, const float* const* clouds, const int* ns, const int32_t* const* perms, int nclouds,
+                   const double* radius, int S, const double* pw_hint)
+{
     if (nclouds < 1 || nclouds > 2 || S < 1 || nclouds * S > c->ball_nsets) {
         bx_set_error("bxk_ball_prepare: %d clouds x %d scales exceed the context's %d grid sets", nclouds, S, c->ball_nsets);
         return BX_ERR_ARG;
     }
     BallBatch B;
-    memset(&B, 0, sizeof(B));
+    batch_from_ctx(c, B);
     int nmax = 0;
     for (int cl = 0; cl < nclouds; ++cl) {
         if (ns[cl] <= 0 || ns[cl] > c->p.max_points) { bx_set_error("bxk_ball_prepare: n=%d outside [1, max_points=%d]", ns[cl], c->p.max_points); return BX_ERR_ARG; }
         if (ball_logc(ns[cl]) > 8) { bx_set_error("bxk_ball_prepare: cloud of %d points exceeds the 1M-point bitmap", ns[cl]); return BX_ERR_ARG; }
-        B.pts[cl] = clouds[cl]; B.perm[cl] = perms ? perms[cl] : nullptr; B.kpts[cl] = kpts[cl]; B.n[cl] = ns[cl];
+        B.pts[cl] = clouds[cl]; B.perm[cl] = perms ? perms[cl] : nullptr; B.n[cl] = ns[cl];
         nmax = ns[cl] > nmax ? ns[cl] : nmax;
     }
-    B.S = S; B.nsets = nclouds * S; B.K = K; B.radius = radius;
-    B.bbox_part = c->ball_bbox_part; B.grid = c->ball_grid; B.cnt = c->ball_cnt; B.start = c->ball_start; B.bsum = c->ball_bsum;
-    B.cellrank = c->ball_cellrank; B.pts4 = c->ball_pts4; B.sorted = c->ball_sorted; B.ptab = c->ball_ptab; B.pnum = c->ball_pnum;
-    B.st_cnt = c->ball_st_cnt; B.st_bsum = c->ball_st_bsum; B.st_pts = c->ball_st_pts; B.st_tab = c->ball_st_tab; B.st_num = c->ball_st_num;
+    B.S = S; B.nsets = nclouds * S; B.radius = radius;
     for (int i = 0; i < S; ++i) {
         // piece width by the share of the cloud a ball of this scale is expected to hold (its cell rows are ~1/40 of that): the
         // percentage thresholds of the pair path (cfg.patch.search_radius_thresholds), 64 when unknown (stage entry point)
         const double thr = pw_hint ? pw_hint[i] : 100.0;
         const int lp = thr >= 3.5 ? 6 : (thr >= 1.0 ? 4 : 3);
-        B.logpw[i] = lp;
         for (int cl = 0; cl < nclouds; ++cl) c->ball_logpw[cl * S + i] = lp;
     }
     const int nb = (nmax + 255) / 256;
@@ -710,26 +716,53 @@ int bxk_ball_prepare(bx_ctx* c, hipStream_t s, const float* const* clouds, const
     hipLaunchKernelGGL(scan_sums_kernel, dim3(ntile, B.nsets), dim3(256), 0, s, B);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(ntile, B.nsets), dim3(256), 0, s, B);
     hipLaunchKernelGGL(cell_scatter_kernel, dim3(nb, B.nsets), dim3(256), 0, s, B);
+    BX_LAUNCH_CHECK();
+    return BX_OK;
+}
+
+// Candidate piece tables of keypoints [k0, k0 + K) of every prepared set (one launch); kpts: per cloud, the whole keypoint array.
+int bxk_ball_rows(bx_ctx* c, hipStream_t s, const float* const* kpts, int nclouds, int S, int k0, int K)
+{
+    if (K <= 0) return BX_OK;
+    if (k0 < 0 || (size_t)(k0 + K) > c->ball_st_num) { bx_set_error("bxk_ball_rows: keypoints [%d, %d) exceed the table", k0, k0 + K); return BX_ERR_ARG; }
+    BallBatch B;
+    batch_from_ctx(c, B);
+    B.S = S; B.nsets = nclouds * S; B.K = K;
+    for (int cl = 0; cl < nclouds; ++cl) B.kpts[cl] = kpts[cl] + (size_t)k0 * 3;
+    for (int i = 0; i < S; ++i) B.logpw[i] = c->ball_logpw[i];
+    B.ptab += (size_t)k0 * NPMAX;       // the same shift inside every set
+    B.pnum += k0;
     hipLaunchKernelGGL(ball_rows_kernel, dim3((K + 3) / 4, B.nsets), dim3(256), 0, s, B, bx_ball_trim());
     BX_LAUNCH_CHECK();
     return BX_OK;
 }
 
+int bxk_ball_prepare(bx_ctx* c, hipStream_t s, const float* const* clouds, const int* ns, const int32_t* const* perms,
+                     const float* const* kpts, int nclouds, int K, const double* radius, int S, const double* pw_hint)
+{
+    if (K <= 0) return BX_OK;
+    int rc = bxk_ball_grids(c, s, clouds, ns, perms, nclouds, radius, S, pw_hint);
+    if (rc != BX_OK) return rc;
+    return bxk_ball_rows(c, s, kpts, nclouds, S, 0, K);
+}
+
 // The query of one prepared set: n = size of its cloud, radius = device pointer to the radius of its scale.
-int bxk_ball_query(bx_ctx* c, hipStream_t s, int set, int n, const float* kpts, int K, const double* radius, int P,
+// Keypoints [k0, k0 + K) of the set (kpts = the whole keypoint array); rows of idx_out / patches_out are relative to k0.
+int bxk_ball_query(bx_ctx* c, hipStream_t s, int set, int n, const float* kpts, int k0, int K, const double* radius, int P,
                    int32_t* idx_out, float* patches_out)
 {
     if (K <= 0) return BX_OK;
+    kpts += (size_t)k0 * 3;
     if (P < 2) { bx_set_error("bxk_ball_query: P=%d", P); return BX_ERR_ARG; }
     bx_prof_mark(c, s, 12, 1);
     int rc = BX_OK;
     switch (ball_logc(n)) {
-    case 3: rc = launch_query<3>(c, s, set, K, kpts, radius, P, idx_out, patches_out); break;
-    case 4: rc = launch_query<4>(c, s, set, K, kpts, radius, P, idx_out, patches_out); break;
-    case 5: rc = launch_query<5>(c, s, set, K, kpts, radius, P, idx_out, patches_out); break;
-    case 6: rc = launch_query<6>(c, s, set, K, kpts, radius, P, idx_out, patches_out); break;
-    case 7: rc = launch_query<7>(c, s, set, K, kpts, radius, P, idx_out, patches_out); break;
-    default: rc = launch_query<8>(c, s, set, K, kpts, radius, P, idx_out, patches_out); break;
+    case 3: rc = launch_query<3>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out); break;
+    case 4: rc = launch_query<4>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out); break;
+    case 5: rc = launch_query<5>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out); break;
+    case 6: rc = launch_query<6>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out); break;
+    case 7: rc = launch_query<7>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out); break;
+    default: rc = launch_query<8>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out); break;
     }
     bx_prof_mark(c, s, 12, 0);
     return rc;
@@ -746,5 +779,5 @@ int bxk_ball_group(bx_ctx* c, hipStream_t s, const float* pts_perm, int n, const
     const int ns[1] = {n};
     int rc = bxk_ball_prepare(c, s, cl, ns, nullptr, kp, 1, K, radius, 1, nullptr);
     if (rc != BX_OK) return rc;
-    return bxk_ball_query(c, s, 0, n, kpts, K, radius, P, idx_out, patches_out);
+    return bxk_ball_query(c, s, 0, n, kpts, 0, K, radius, P, idx_out, patches_out);
 }

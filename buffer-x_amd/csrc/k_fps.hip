@@ -38,7 +38,9 @@ struct FpsArgs {
     int G[FPS_MAX_CLOUDS];
     int wg_start[FPS_MAX_CLOUDS + 1];
     int nclouds;
-    int m;
+    int j0, m;                  // iterations [j0, m) of this launch; j0 > 0 resumes from td_state + kpts_out[j0 - 1]
+    int save;                   // store the running min-distances into td_state at the end (another launch follows)
+    float* td_state[FPS_MAX_CLOUDS];   // [n] running min-distance of every point between the launches of a tiled run
     unsigned long long* slots;  // [cloud][parity 2][FPS_MAX_G][5] granules
     int32_t* err_flag;
 };
@@ -115,18 +117,22 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
             pz[i] = xyz[(size_t)k * 3 + 2];
             float mag = (px[i] * px[i] + py[i] * py[i]) + pz[i] * pz[i];
             td[i] = (mag <= 1e-3f) ? -1.0f : 1e10f;  // -1 marks "never a candidate" (upstream `continue`)
+            if (a.j0 > 0) td[i] = a.td_state[cloud][k];
         } else {
             px[i] = 0.f; py[i] = 0.f; pz[i] = 0.f; td[i] = -1.0f;
         }
     }
     float cx = xyz[0], cy = xyz[1], cz = xyz[2];
-    if (g == 0 && t == 0) {
+    if (a.j0 > 0) {   // the previous launch of this stream wrote the last keypoint (kernel boundary: visible)
+        const float* lk = a.kpts_out[cloud] + (size_t)(a.j0 - 1) * 3;
+        cx = lk[0]; cy = lk[1]; cz = lk[2];
+    } else if (g == 0 && t == 0) {
         a.idx_out[cloud][0] = 0;
         if (a.kpts_out[cloud]) { a.kpts_out[cloud][0] = cx; a.kpts_out[cloud][1] = cy; a.kpts_out[cloud][2] = cz; }
     }
     unsigned long long* slots = a.slots + (size_t)cloud * 2 * FPS_MAX_G * 5;
 
-    for (int j = 1; j < a.m; ++j) {
+    for (int j = a.j0 > 0 ? a.j0 : 1; j < a.m; ++j) {
         const int par = j & 1;
         float bd = -1.0f, bx = 0.f, by = 0.f, bz = 0.f;
         int bi = 0;
@@ -252,6 +258,13 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
             }
         }
     }
+    if (a.save) {
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            int k = base + i * FPS_THREADS + t;
+            if (k < n) a.td_state[cloud][k] = td[i];
+        }
+    }
 }
 
 __global__ void gather_rows_kernel(const float* __restrict__ pts, const int32_t* __restrict__ idx, int n, float* __restrict__ out)
@@ -267,13 +280,21 @@ __global__ void gather_rows_kernel(const float* __restrict__ pts, const int32_t*
 
 }  // namespace
 
-int bxk_fps(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* n, int nclouds, int m, int32_t* const* idx_out,
-            float* const* kpts_out)
+// Iterations [j0, j1) of an m-point run.  A run may be cut into consecutive launches on ONE stream (latency mode of
+// bx_register_pair: the descriptors of the first keypoints are computed while the later ones are still being sampled): launches
+// with j1 < m leave the running min-distances in c->fps_td, launches with j0 > 0 pick them up.  The result is the single-launch
+// one bit for bit (same per-thread state, same epochs in the exchange slots).
+int bxk_fps_range(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* n, int nclouds, int j0, int j1, int m,
+                  int32_t* const* idx_out, float* const* kpts_out)
 {
     if (nclouds < 1 || nclouds > FPS_MAX_CLOUDS) { bx_set_error("bxk_fps: nclouds"); return BX_ERR_ARG; }
+    if (j0 < 0 || j1 <= j0 || j1 > m) { bx_set_error("bxk_fps: range [%d, %d) of %d", j0, j1, m); return BX_ERR_ARG; }
+    if ((j0 > 0 || j1 < m) && (!kpts_out || !c->fps_td[0])) { bx_set_error("bxk_fps: a tiled run needs kpts_out and the td state"); return BX_ERR_ARG; }
     FpsArgs a{};
     a.nclouds = nclouds;
-    a.m = m;
+    a.j0 = j0;
+    a.m = j1;
+    a.save = j1 < m ? 1 : 0;
     a.slots = c->fps_slots;
     a.err_flag = c->err_flag;
     int ppt = 4;
@@ -292,17 +313,38 @@ int bxk_fps(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* n, int
         a.n[i] = n[i];
         a.idx_out[i] = idx_out[i];
         a.kpts_out[i] = kpts_out ? kpts_out[i] : nullptr;
+        a.td_state[i] = c->fps_td[i];
         a.G[i] = (n[i] + FPS_THREADS * ppt - 1) / (FPS_THREADS * ppt);
         a.wg_start[i] = total;
         total += a.G[i];
     }
     a.wg_start[nclouds] = total;
-    BX_HIP(hipMemsetAsync(c->fps_slots, 0, sizeof(unsigned long long) * FPS_MAX_CLOUDS * 2 * FPS_MAX_G * 5, s));
-    if (ppt == 4) hipLaunchKernelGGL(fps_kernel<4>, dim3(total), dim3(FPS_THREADS), 0, s, a);
-    else if (ppt == 8) hipLaunchKernelGGL(fps_kernel<8>, dim3(total), dim3(FPS_THREADS), 0, s, a);
-    else hipLaunchKernelGGL(fps_kernel<16>, dim3(total), dim3(FPS_THREADS), 0, s, a);
+    // epochs continue across the launches of a tiled run: the slots are cleared once, in front of the first one
+    if (j0 == 0) BX_HIP(hipMemsetAsync(c->fps_slots, 0, sizeof(unsigned long long) * FPS_MAX_CLOUDS * 2 * FPS_MAX_G * 5, s));
+    static int hog = -1;
+    if (hog < 0) { const char* e = getenv("BX_FPS_HOG"); hog = e ? atoi(e) : 0; }
+    size_t lds = 0;
+    if (hog > 0 && (j0 > 0 || j1 < m)) {
+        lds = (size_t)hog * 1024;
+        static bool attr = false;
+        if (!attr) {
+            BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+            BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+            BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+            attr = true;
+        }
+    }
+    if (ppt == 4) hipLaunchKernelGGL(fps_kernel<4>, dim3(total), dim3(FPS_THREADS), lds, s, a);
+    else if (ppt == 8) hipLaunchKernelGGL(fps_kernel<8>, dim3(total), dim3(FPS_THREADS), lds, s, a);
+    else hipLaunchKernelGGL(fps_kernel<16>, dim3(total), dim3(FPS_THREADS), lds, s, a);
     BX_LAUNCH_CHECK();
     return BX_OK;
+}
+
+int bxk_fps(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* n, int nclouds, int m, int32_t* const* idx_out,
+            float* const* kpts_out)
+{
+    return bxk_fps_range(c, s, xyz, n, nclouds, 0, m, m, idx_out, kpts_out);
 }
 
 int bxk_gather_rows(hipStream_t s, const float* pts, const int32_t* idx, int n, float* out)

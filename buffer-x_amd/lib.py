@@ -24,7 +24,8 @@ class BxParams(C.Structure):
                 ("dist_th", C.c_double), ("inlier_th", C.c_double), ("similar_th", C.c_double),
                 ("confidence", C.c_double), ("iter_n", C.c_int32), ("enable_early_exit", C.c_int32),
                 ("early_exit_min_inliers", C.c_int32), ("pose_refine", C.c_int32), ("max_points", C.c_int32),
-                ("pose_estimator", C.c_int32), ("kiss_resolution", C.c_double)]
+                ("pose_estimator", C.c_int32), ("kiss_resolution", C.c_double),
+                ("keypoint_tiles", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class BxWeights(C.Structure):
@@ -123,6 +124,8 @@ def params_from_cfg(cfg, max_points):
         raise ValueError(f"Unknown pose estimator: {est}")           # models/pose_estimator.py:48
     p.pose_estimator = 1 if est == "kiss_matcher" else 0
     p.kiss_resolution = float(cfg.match.get("kiss_resolution", 0.3))
+    # not a reference option: 2..8 = latency form of the whole-pair call (FPS beside the descriptor work), see include/bufferx.h
+    p.keypoint_tiles = int(cfg.test.get("keypoint_tiles", 0))
     return p
 
 

@@ -85,7 +85,8 @@ class BufferX(nn.Module):
                tuple(cfg.patch.search_radius_thresholds), cfg.match.dist_th, cfg.match.inlier_th, cfg.match.similar_th,
                cfg.match.confidence, cfg.match.iter_n, bool(cfg.match.get("enable_early_exit", True)),
                cfg.match.get("early_exit_min_inliers", 15), cfg.test.pose_refine is True,
-               cfg.match.get("pose_estimator", "ransac"), cfg.match.get("kiss_resolution", 0.3))
+               cfg.match.get("pose_estimator", "ransac"), cfg.match.get("kiss_resolution", 0.3),
+               cfg.test.get("keypoint_tiles", 0))
         cap = self._max_points or 0
         if self._ctx is not None and self._ctx_key == key and n_max <= self._ctx_cap:
             return self._ctx

@@ -41,6 +41,7 @@ extern "C" {
 #define BX_ERR_DEVICE 4    /* device-side failure flag (spin timeout, ...) */
 
 #define BX_MAX_SCALES 8
+#define BX_MAX_TILES 8
 
 typedef struct bx_ctx bx_ctx;
 typedef struct bx_lane bx_lane;
@@ -66,6 +67,12 @@ typedef struct bx_params {
     int32_t max_points;                   /* workspace sizing: largest cloud this context will see */
     int32_t pose_estimator;               /* cfg.match.pose_estimator: 0 = "ransac", 1 = "kiss_matcher" (utils/test_args.py:74-80) */
     double kiss_resolution;               /* cfg.match.kiss_resolution (KISSMatcherConfig(resolution), models/pose_estimator.py:61) */
+    int32_t keypoint_tiles;               /* no reference counterpart.  0/1: throughput form of bx_register_pair (everything on the
+                                           * caller's stream).  2..BX_MAX_TILES: latency form -- furthest point sampling runs on an
+                                           * internal stream in that many launches (the first ends at num_points_radius_estimate)
+                                           * and the descriptors of a tile of keypoints are computed while the next tile is still
+                                           * being sampled.  Results are bit-identical in both forms. */
+    int32_t reserved0;
 } bx_params;
 
 /* BatchNorm-folded weights in kernel layout, HOST pointers (buffer-x_amd/weights.py: fold_and_pack).

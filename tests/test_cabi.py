@@ -27,8 +27,8 @@ def test_header_symbols_exported():
 def test_struct_layouts_match_header():
     from bufferx_amd import lib
     # bx_params: 8 int32, 1+8+3+1 doubles, 6 int32, 1 double ; bx_result: 16 doubles + 8 int32 + 8 floats
-    assert C.sizeof(lib.BxParams) == 8 * 4 + 13 * 8 + 6 * 4 + 8
-    assert lib.BxParams.pose_estimator.offset == 156 and lib.BxParams.kiss_resolution.offset == 160
+    assert C.sizeof(lib.BxParams) == 8 * 4 + 13 * 8 + 6 * 4 + 8 + 8
+    assert lib.BxParams.pose_estimator.offset == 156 and lib.BxParams.kiss_resolution.offset == 160 and lib.BxParams.keypoint_tiles.offset == 168
     assert C.sizeof(lib.BxResult) == 16 * 8 + 8 * 4 + 8 * 4
     assert lib.BxParams.delta.offset == 32 and lib.BxParams.confidence.offset == 32 + 8 * 12
 
