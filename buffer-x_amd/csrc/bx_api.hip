@@ -105,6 +105,7 @@ void carve(bx_ctx* c, char* base, size_t* total)
     c->patches2 = tiled ? cv.take<float>(K * P * 3) : nullptr;
     c->feat2 = tiled ? cv.take<float>(K * BX_RAD * BX_EA * 16) : nullptr;
     for (int i = 0; i < 2; ++i) c->act2[i] = tiled ? cv.take<float>(K * 8 * BX_EA * 16) : nullptr;   // largest Cylindrical_Net map: 128 channels
+    for (int i = 0; i < 2; ++i) c->act3[i] = tiled ? cv.take<float>(K * 8 * BX_EA * 16) : nullptr;
     c->s_mids = cv.take<int32_t>(K);
     c->t_mids = cv.take<int32_t>(K);
     c->ind = cv.take<float>(K);
@@ -117,7 +118,8 @@ void carve(bx_ctx* c, char* base, size_t* total)
     c->inlier_ind = cv.take<int32_t>(SK);
     c->rad_hist = cv.take<unsigned long long>(8200);
     c->fps_dist = nullptr;
-    c->fps_slots = cv.take<unsigned long long>(2 * 2 * 64 * 5);      // k_fps.hip: [cloud][parity][FPS_MAX_G][5]
+    c->fps_slots = cv.take<unsigned long long>(2 * 2 * 64 * 8);      // k_fps.hip: [cloud][parity][FPS_MAX_G][FPS_REC]
+    c->fps_hello = cv.take<unsigned long long>(2 * 64);
     c->ransac_inl = cv.take<int32_t>(BX_RANSAC_BATCH);
     c->ransac_err = cv.take<double>(BX_RANSAC_BATCH);
     c->ransac_T = cv.take<double>((size_t)BX_RANSAC_BATCH * 12);
@@ -302,10 +304,10 @@ int check_ctx(bx_ctx* c, bool need_weights)
     return BX_OK;
 }
 
-int desc_stack(bx_ctx* c, hipStream_t s, const float* feat, int K, float* desc, float* equi, float* x_out, int scratch = 0)
+int desc_stack(bx_ctx* c, hipStream_t s, const float* feat, int K, float* desc, float* equi, float* x_out, float* const* scratch = nullptr)
 {
     const float* in = feat;
-    float* bufs[2] = {scratch ? c->act2[0] : c->act0, scratch ? c->act2[1] : c->act1};
+    float* bufs[2] = {scratch ? scratch[0] : c->act0, scratch ? scratch[1] : c->act1};
     int rc;
     for (int l = 0; l < BX_NDESC; ++l) {
         float* out = bufs[l & 1];
@@ -389,6 +391,10 @@ static int create_impl(bx_ctx* c, int device_id)
         BX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));      // hi = numerically lowest = most urgent
         BX_HIP(hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, hi));
         BX_HIP(hipStreamCreateWithFlags(&c->tgt_stream, hipStreamNonBlocking));
+        BX_HIP(hipStreamCreateWithFlags(&c->match_stream, hipStreamNonBlocking));
+        BX_HIP(hipEventCreateWithFlags(&c->ev_match_done, hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < BX_MAX_SCALES; ++j) BX_HIP(hipEventCreateWithFlags(&c->ev_desc[i][j], hipEventDisableTiming));
         BX_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         BX_HIP(hipEventCreateWithFlags(&c->ev_tgt_go, hipEventDisableTiming));
         BX_HIP(hipEventCreateWithFlags(&c->ev_tgt_done, hipEventDisableTiming));
@@ -454,6 +460,10 @@ int bx_destroy(bx_ctx* c)
     }
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->tgt_stream) (void)hipStreamDestroy(c->tgt_stream);
+    if (c->match_stream) (void)hipStreamDestroy(c->match_stream);
+    if (c->ev_match_done) (void)hipEventDestroy(c->ev_match_done);
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < BX_MAX_SCALES; ++j) if (c->ev_desc[i][j]) (void)hipEventDestroy(c->ev_desc[i][j]);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_tgt_go) (void)hipEventDestroy(c->ev_tgt_go);
     if (c->ev_tgt_done) (void)hipEventDestroy(c->ev_tgt_done);
@@ -873,9 +883,10 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
             if ((rc = cap_copy(ds, c->cap.patches, patches, (size_t)K * P * 3)) != BX_OK) return rc;
             if ((rc = cap_copy(ds, c->cap.feat, feat, (size_t)K * BX_RAD * BX_EA * 16)) != BX_OK) return rc;
         }
-        if (side) {
+        if (tiled) {
             ProfScope ps(c, ds, 4);
-            if ((rc = desc_stack(c, ds, feat, kn, c->desc_sc[i][cl] + (size_t)k0 * 32, c->equi_sc[i][cl] + (size_t)k0 * BX_EA * 32, nullptr, 1)) != BX_OK) return rc;
+            if ((rc = desc_stack(c, ds, feat, kn, c->desc_sc[i][cl] + (size_t)k0 * 32, c->equi_sc[i][cl] + (size_t)k0 * BX_EA * 32, nullptr, side ? c->act2 : c->act3)) != BX_OK) return rc;
+            if (k0 + kn == K) BX_HIP(hipEventRecord(c->ev_desc[cl][i], ds));     // this (cloud, scale) is complete
         } else {
             LaneScope ls(c, ds, 2); ProfScope ps(c, ds, 4);
             if ((rc = desc_stack(c, ds, feat, kn, c->desc_sc[i][cl] + (size_t)k0 * 32, c->equi_sc[i][cl] + (size_t)k0 * BX_EA * 32, capc ? c->cap.x : nullptr)) != BX_OK) return rc;
@@ -908,9 +919,18 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
             for (int cl = 0; cl < 2; ++cl)
                 if ((rc = describe(i, cl, k0, kn)) != BX_OK) return rc;
     }
-    if ((rc = tgt_join()) != BX_OK) return rc;
+    // no early exit: nothing of a scale's matching decides what the later scales do -- it runs on the third stream, beside the
+    // descriptor work still queued on the other two, and only the last scale's matching is exposed
+    hipStream_t s_caller = s;
+    const bool split_match = tiled && !early;
+    if (!split_match) { if ((rc = tgt_join()) != BX_OK) return rc; }
     int ransac_calls = 0;
+    if (split_match) s = c->match_stream;
     for (int i = 0; i < S; ++i) {
+        if (split_match) {
+            BX_HIP(hipStreamWaitEvent(s, c->ev_desc[0][i], 0));
+            BX_HIP(hipStreamWaitEvent(s, c->ev_desc[1][i], 0));
+        }
         c->skip = (early && i > 0) ? &st->done : nullptr;
         const bool capi = c->cap_on && c->cap.scale == i;
         if (!tiled || (early && i > 0)) {
@@ -956,6 +976,12 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
             ++ransac_calls;
             hipLaunchKernelGGL(early_exit_kernel, dim3(1), dim3(64), 0, s, st, p.early_exit_min_inliers);
         }
+    }
+    if (split_match) {
+        BX_HIP(hipEventRecord(c->ev_match_done, s));
+        s = s_caller;
+        BX_HIP(hipStreamWaitEvent(s, c->ev_match_done, 0));
+        if ((rc = tgt_join()) != BX_OK) return rc;
     }
     // final pose estimation unless the early exit was taken (models/BUFFERX.py:449-457)
     { ProfScope ps(c, s, 9);

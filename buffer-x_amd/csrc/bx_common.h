@@ -131,8 +131,10 @@ struct bx_ctx {
     float* fps_td[2];                   // [max_points] running min-distances between the launches of a tiled FPS run (else null)
     hipStream_t aux_stream;             // latency mode: the FPS launches run here, beside the descriptor work of the caller's stream
     hipStream_t tgt_stream;             // latency mode: the target cloud's descriptor chain (the source cloud's stays on the caller's)
-    hipEvent_t ev_fork, ev_tile[BX_MAX_TILES], ev_tgt_go, ev_tgt_done;
+    hipStream_t match_stream;           // latency mode without early exit: matching + CostNet of scale i beside the descriptor work of i+1..
+    hipEvent_t ev_fork, ev_tile[BX_MAX_TILES], ev_tgt_go, ev_tgt_done, ev_desc[2][BX_MAX_SCALES], ev_match_done;
     float *patches2, *feat2, *act2[2];  // latency mode: scratch of the target cloud's chain
+    float* act3[2];                     // latency mode: conv ping-pong of the source cloud's chain (act0/act1 stay with the CostNet)
     unsigned long long* nn_key[2];      // [K]
     int32_t *s_mids, *t_mids;           // [K]
     float* ind;                         // [K]
@@ -143,6 +145,8 @@ struct bx_ctx {
     unsigned long long* rad_hist;       // [8200]
     float* fps_dist;                    // [2][max_points]  (unused by register path; kept for generic path)
     unsigned long long* fps_slots;      // cross-workgroup exchange granules
+    unsigned long long* fps_hello;      // [2][64] placement handshake granules (k_fps.hip)
+    int fps_rot;                        // rotates the XCD pair the co-located FPS launches of this context aim at
     int32_t* ransac_inl;                // [RANSAC_BATCH]
     double* ransac_err;                 // [RANSAC_BATCH]
     double* ransac_T;                   // [RANSAC_BATCH][12]

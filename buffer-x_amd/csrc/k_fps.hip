@@ -19,6 +19,12 @@
 //     loads -- the "R2 granule" hand-off of the CDNA4 guide: no fence, placement independent, spins
 //     bounded.  Slots are double-buffered by iteration parity and zeroed by a memset node before launch.  All G workgroups of a
 //     cloud must be resident at once (they wait for each other): G <= 64 per cloud, 2 clouds, 256 CUs.
+//   * XCD co-location (clouds of up to 32 workgroups): the launch is 8 x G blocks and only the blocks with blockIdx % 8 == x do
+//     work, so that the G workgroups of a cloud land on ONE XCD (observed dispatch order: block b -> XCD b % 8; nothing relies on
+//     it).  Every workgroup reads its XCC id and the workgroups of a cloud exchange the ids through the agent-scope granules; only
+//     if all G ids agree do they switch to the L2 protocol -- plain write-through stores, polls = buffer_inv sc1 + plain load --
+//     which never leaves the XCD's L2 (measured all-to-all round, G = 3: 0.57 us against 1.12 us across XCDs).  Any other
+//     placement keeps the agent-scope protocol: correctness never depends on where the blocks run.
 #include "bx_common.h"
 
 namespace {
@@ -26,7 +32,7 @@ namespace {
 constexpr int FPS_THREADS = 1024;
 constexpr int FPS_WAVES = FPS_THREADS / 64;
 constexpr int FPS_MAX_G = 64;            // 64 workgroups x 16 384 points = 1 048 576 points per cloud (the neighbour bitmap's limit too)
-constexpr int FPS_NR = (5 * FPS_MAX_G + 63) / 64;   // polling rounds: one granule per lane and round
+constexpr int FPS_REC = 8;               // 8-byte words per exchange record: five {epoch, value} granules in one 64-byte line
 constexpr int FPS_MAX_CLOUDS = 2;
 constexpr unsigned FPS_SPIN_LIMIT = 1u << 24;
 
@@ -41,7 +47,11 @@ struct FpsArgs {
     int j0, m;                  // iterations [j0, m) of this launch; j0 > 0 resumes from td_state + kpts_out[j0 - 1]
     int save;                   // store the running min-distances into td_state at the end (another launch follows)
     float* td_state[FPS_MAX_CLOUDS];   // [n] running min-distance of every point between the launches of a tiled run
-    unsigned long long* slots;  // [cloud][parity 2][FPS_MAX_G][5] granules
+    unsigned long long* slots;  // [cloud][parity 2][FPS_MAX_G][FPS_REC] granules
+    int colocate;               // 1: grid = 8 x max G, the workgroups of cloud c are the blocks with blockIdx % 8 == xcd[c]
+    int xcd[FPS_MAX_CLOUDS];
+    unsigned long long* hello;  // [cloud][FPS_MAX_G] placement handshake granules, zeroed in front of every launch
+    long long* dbg;             // BX_FPS_TRACE: cycle stamps of iterations 1000..1007 of workgroup 0 ([8][8])
     int32_t* err_flag;
 };
 
@@ -81,8 +91,32 @@ __device__ __forceinline__ long long wave_max_key(long long key)
     const int hi = (int)(key >> 32);
     const unsigned lo = (unsigned)((unsigned long long)key & 0xffffffffu);
     const int mh = wave_max_i32(hi);
-    const unsigned ml = wave_max_u32(hi == mh ? lo : 0u);
+    // one lane holds the largest distance almost always: its low word is the answer; ties go through the second reduction
+    const unsigned long long bal = __ballot(hi == mh);
+    unsigned ml;
+    if ((bal & (bal - 1ULL)) == 0ULL) ml = (unsigned)__builtin_amdgcn_readlane((int)lo, __ffsll((long long)bal) - 1);
+    else ml = wave_max_u32(hi == mh ? lo : 0u);
     return (long long)(((unsigned long long)(unsigned)mh << 32) | ml);
+}
+
+__device__ __forceinline__ unsigned xcc_id()
+{
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xfu;
+}
+// granule store / load of the two protocols (fast = all workgroups of the cloud share one XCD's L2)
+__device__ __forceinline__ void granule_store(unsigned long long* p, unsigned long long v, bool fast)
+{
+    if (fast) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long granule_load(unsigned long long* p, bool fast)
+{
+    unsigned long long x;
+    if (fast) asm volatile("buffer_inv sc1\n\tglobal_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(p) : "memory");
+    else x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return x;
 }
 
 template <int PPT>
@@ -93,9 +127,18 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
     __shared__ long long s_fkey[2];
     __shared__ float s_fxyz[2][3];
 
-    int cloud = 0;
-    if (a.nclouds > 1 && (int)blockIdx.x >= a.wg_start[1]) cloud = 1;
-    const int g = blockIdx.x - a.wg_start[cloud];
+    int cloud = 0, g;
+    if (a.colocate) {
+        const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        cloud = -1;
+        for (int cl = 0; cl < a.nclouds; ++cl)
+            if (x == a.xcd[cl] && slot < a.G[cl]) cloud = cl;
+        if (cloud < 0) return;
+        g = slot;
+    } else {
+        if (a.nclouds > 1 && (int)blockIdx.x >= a.wg_start[1]) cloud = 1;
+        g = blockIdx.x - a.wg_start[cloud];
+    }
     const int G = a.G[cloud];
     const int n = a.n[cloud];
     const float* __restrict__ xyz = a.xyz[cloud];
@@ -130,10 +173,43 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
         a.idx_out[cloud][0] = 0;
         if (a.kpts_out[cloud]) { a.kpts_out[cloud][0] = cx; a.kpts_out[cloud][1] = cy; a.kpts_out[cloud][2] = cz; }
     }
-    unsigned long long* slots = a.slots + (size_t)cloud * 2 * FPS_MAX_G * 5;
+    unsigned long long* slots = a.slots + (size_t)cloud * 2 * FPS_MAX_G * FPS_REC;
+    // placement handshake: do all G workgroups of this cloud sit on one XCD?
+    bool fast = false;
+    if (a.colocate && G > 1) {
+        __shared__ int s_fast;
+        if (wave == 0) {
+            unsigned long long* hello = a.hello + (size_t)cloud * FPS_MAX_G;
+            const unsigned me = xcc_id();
+            if (lane == 0) __hip_atomic_store(hello + g, 0x100000000ULL | me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool same = true, fail = false;
+            unsigned spins = 0;
+            while (true) {
+                bool ok = true;
+                if (lane < G) {
+                    const unsigned long long x = __hip_atomic_load(hello + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = (x >> 32) != 0;
+                    same = (unsigned)x == me;
+                }
+                if (__all(ok)) break;
+                if (++spins > FPS_SPIN_LIMIT) { fail = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (fail && lane == 0) atomicOr(a.err_flag, 1);
+            const bool all_same = __all(same) && !fail;
+            if (lane == 0) s_fast = all_same ? 1 : 0;
+        }
+        __syncthreads();
+        fast = s_fast != 0;
+    }
+    if (a.dbg && blockIdx.x == 0 && t == 0) a.dbg[63] = (fast ? 1 : 0) + 2 * a.colocate + 100 * G;
 
     for (int j = a.j0 > 0 ? a.j0 : 1; j < a.m; ++j) {
         const int par = j & 1;
+        const bool tr = a.dbg != nullptr && blockIdx.x == 0 && t == 0 && j >= 1000 && j < 1008;
+        long long* tdp = a.dbg + (j - 1000) * 8;
+#define FPS_TR(q) do { if (tr) tdp[q] = __builtin_readcyclecounter(); } while (0)
+        FPS_TR(0);
         float bd = -1.0f, bx = 0.f, by = 0.f, bz = 0.f;
         int bi = 0;
 #pragma unroll
@@ -149,6 +225,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
             by = better ? py[i] : by;
             bz = better ? pz[i] : bz;
         }
+        FPS_TR(1);
         unsigned k = (unsigned)(base + bi * FPS_THREADS + t);
         unsigned tb = ((k & tmask) << 23) | (k >> lt);
         long long key = ((long long)__float_as_int(bd) << 32) | (long long)(unsigned)(~tb);
@@ -158,7 +235,9 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
             s_key[par][wave] = wk;
             s_xyz[par][wave][0] = bx; s_xyz[par][wave][1] = by; s_xyz[par][wave][2] = bz;
         }
+        FPS_TR(2);
         __syncthreads();
+        FPS_TR(3);
         long long fk;
         float fx, fy, fz;
         if (G == 1) {
@@ -180,66 +259,69 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                 // the (unique, or lowest) lane holding the max publishes this workgroup's record
                 unsigned long long bal = __ballot(lane < FPS_WAVES && k0 == mk);
                 int src = __ffsll((long long)bal) - 1;
-                unsigned long long* my = slots + ((size_t)par * FPS_MAX_G + g) * 5;
-                if (lane == src) {
-                    unsigned ep = (unsigned)j;
-                    unsigned v[5] = {(unsigned)((unsigned long long)mk >> 32), (unsigned)((unsigned long long)mk & 0xffffffffu),
-                                     __float_as_uint(s_xyz[par][lane][0]), __float_as_uint(s_xyz[par][lane][1]),
-                                     __float_as_uint(s_xyz[par][lane][2])};
-#pragma unroll
-                    for (int q = 0; q < 5; ++q)
-                        __hip_atomic_store(my + q, ((unsigned long long)ep << 32) | v[q], __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long* my = slots + ((size_t)par * FPS_MAX_G + g) * FPS_REC;
+                {   // lanes 0..4 store one granule each: one store instruction, one 40-byte write
+                    const unsigned sx = __float_as_uint(s_xyz[par][src][0]), sy = __float_as_uint(s_xyz[par][src][1]);
+                    const unsigned sz = __float_as_uint(s_xyz[par][src][2]);
+                    const unsigned khi = (unsigned)((unsigned long long)mk >> 32), klo = (unsigned)((unsigned long long)mk & 0xffffffffu);
+                    const unsigned v = lane == 0 ? khi : (lane == 1 ? klo : (lane == 2 ? sx : (lane == 3 ? sy : sz)));
+                    if (lane < 5) granule_store(my + lane, ((unsigned long long)(unsigned)j << 32) | v, fast);
                 }
-                // poll all G records (one granule per lane and round; rounds beyond 5G granules are skipped: G is uniform)
-                unsigned val[FPS_NR];
+                FPS_TR(4);
+                // poll: lane w reads the five granules of record w (one 64-byte line per workgroup), so that the checks, the key and
+                // the reduction over the G records are lane-local / one DPP reduction -- no scalar walk over the records
+                unsigned long long r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0;
                 bool fail = false;
-#pragma unroll
-                for (int r = 0; r < FPS_NR; ++r) {
-                    val[r] = 0;
-                    if (r * 64 >= 5 * G) continue;
-                    int q = lane + r * 64;
-                    bool act = q < 5 * G;
-                    unsigned long long* gp = slots + (size_t)par * FPS_MAX_G * 5 + q;
+                {
+                    const bool act = lane < G;
+                    unsigned long long* rp = slots + ((size_t)par * FPS_MAX_G + lane) * FPS_REC;
                     unsigned spins = 0;
                     while (true) {
                         bool ok = true;
                         if (act) {
-                            unsigned long long x = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            val[r] = (unsigned)x;
-                            ok = (unsigned)(x >> 32) == (unsigned)j;
+                            if (fast) {
+                                asm volatile("buffer_inv sc1\n\t"
+                                             "global_load_dwordx2 %0, %5, off\n\t"
+                                             "global_load_dwordx2 %1, %5, off offset:8\n\t"
+                                             "global_load_dwordx2 %2, %5, off offset:16\n\t"
+                                             "global_load_dwordx2 %3, %5, off offset:24\n\t"
+                                             "global_load_dwordx2 %4, %5, off offset:32\n\t"
+                                             "s_waitcnt vmcnt(0)"
+                                             : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4) : "v"(rp) : "memory");
+                            } else {
+                                r0 = __hip_atomic_load(rp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                r1 = __hip_atomic_load(rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                r2 = __hip_atomic_load(rp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                r3 = __hip_atomic_load(rp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                r4 = __hip_atomic_load(rp + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            const unsigned ep = (unsigned)j;
+                            ok = (unsigned)(r0 >> 32) == ep && (unsigned)(r1 >> 32) == ep && (unsigned)(r2 >> 32) == ep &&
+                                 (unsigned)(r3 >> 32) == ep && (unsigned)(r4 >> 32) == ep;
                         }
                         if (__all(ok)) break;
                         if (++spins > FPS_SPIN_LIMIT) { fail = true; break; }
                         __builtin_amdgcn_s_sleep(1);
                     }
                 }
+                FPS_TR(5);
                 if (fail && lane == 0) atomicOr(a.err_flag, 1);
-                // gather record w: granules 5w..5w+4 -> lanes; reduce
-                long long bestk = (long long)0x8000000000000000LL;
-                float ox = 0.f, oy = 0.f, oz = 0.f;
-                auto granule = [&](int qq) -> unsigned {    // wave-uniform index: v_readlane, no LDS crossbar
-                    if (5 * G <= 64) return (unsigned)__builtin_amdgcn_readlane((int)val[0], qq);   // G <= 12: one polling round
-                    unsigned v = 0;
-#pragma unroll
-                    for (int r = 0; r < FPS_NR; ++r)
-                        if ((qq >> 6) == r) v = (unsigned)__builtin_amdgcn_readlane((int)val[r], qq & 63);   // uniform branch
-                    return v;
-                };
-                for (int w = 0; w < G; ++w) {
-                    const int q0 = 5 * w;
-                    const unsigned hi = granule(q0), lo = granule(q0 + 1);
-                    const unsigned ux = granule(q0 + 2), uy = granule(q0 + 3), uz = granule(q0 + 4);
-                    long long kk = (long long)(((unsigned long long)hi << 32) | lo);
-                    if (kk > bestk) { bestk = kk; ox = __uint_as_float(ux); oy = __uint_as_float(uy); oz = __uint_as_float(uz); }
-                }
+                const long long rk = lane < G ? (long long)(((unsigned long long)(unsigned)r0 << 32) | (unsigned)r1) : (long long)0x8000000000000000LL;
+                const long long bestk = wave_max_key(rk);
+                // keys embed the point index: one lane holds the maximum (the lowest one, should two ever agree)
+                const int wl = __ffsll((long long)__ballot(lane < G && rk == bestk)) - 1;
+                const float ox = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)(unsigned)r2, wl));
+                const float oy = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)(unsigned)r3, wl));
+                const float oz = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)(unsigned)r4, wl));
                 if (lane == 0) {
                     s_fkey[par] = bestk;
                     s_fxyz[par][0] = ox; s_fxyz[par][1] = oy; s_fxyz[par][2] = oz;
                 }
             }
+            FPS_TR(6);
             __syncthreads();
             fk = s_fkey[par]; fx = s_fxyz[par][0]; fy = s_fxyz[par][1]; fz = s_fxyz[par][2];
+            FPS_TR(7);
         }
         int old;
         if (fk < 0) {  // no candidate anywhere (all points within 1e-3 of the origin): upstream yields index 0
@@ -297,16 +379,21 @@ int bxk_fps_range(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* 
     a.save = j1 < m ? 1 : 0;
     a.slots = c->fps_slots;
     a.err_flag = c->err_flag;
+    a.dbg = getenv("BX_FPS_TRACE") ? c->ball_dbg : nullptr;
     int ppt = 4;
     int total = 0;
     int nmax = 0;
     for (int i = 0; i < nclouds; ++i) nmax = n[i] > nmax ? n[i] : nmax;
-    // fewest workgroups first (cross-CU exchange is the expensive part), then the smallest PPT that fits
-    int Gneed = (nmax + FPS_THREADS * 16 - 1) / (FPS_THREADS * 16);
-    if (Gneed < 1) Gneed = 1;
-    if (Gneed > FPS_MAX_G) { bx_set_error("bxk_fps: cloud of %d points exceeds %d", nmax, FPS_MAX_G * FPS_THREADS * 16); return BX_ERR_ARG; }
-    int per_wg = (nmax + Gneed - 1) / Gneed;
-    ppt = per_wg <= FPS_THREADS * 4 ? 4 : (per_wg <= FPS_THREADS * 8 ? 8 : 16);
+    // points per thread: the per-iteration scan is VALU-bound (4 waves per SIMD), the all-to-all exchange grows by ~0.1 us per
+    // workgroup -- measured optimum: the smallest PPT that keeps a cloud within 8 workgroups (K = 5000: 2.0 / 2.2 / 2.3 us per
+    // iteration at 25k / 38k / 55k points)
+    if ((nmax + FPS_THREADS * 16 - 1) / (FPS_THREADS * 16) > FPS_MAX_G) { bx_set_error("bxk_fps: cloud of %d points exceeds %d", nmax, FPS_MAX_G * FPS_THREADS * 16); return BX_ERR_ARG; }
+    ppt = nmax <= 8 * FPS_THREADS * 4 ? 4 : (nmax <= 8 * FPS_THREADS * 8 ? 8 : 16);
+    {
+        const char* e = getenv("BX_FPS_PPT");       // test hook: every PPT instantiation on any cloud size
+        const int force = e ? atoi(e) : 0;
+        if ((force == 4 || force == 8 || force == 16) && (nmax + FPS_THREADS * force - 1) / (FPS_THREADS * force) <= FPS_MAX_G) ppt = force;
+    }
     for (int i = 0; i < nclouds; ++i) {
         if (n[i] < 1) { bx_set_error("bxk_fps: empty cloud"); return BX_ERR_ARG; }
         a.xyz[i] = xyz[i];
@@ -319,21 +406,23 @@ int bxk_fps_range(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* 
         total += a.G[i];
     }
     a.wg_start[nclouds] = total;
-    // epochs continue across the launches of a tiled run: the slots are cleared once, in front of the first one
-    if (j0 == 0) BX_HIP(hipMemsetAsync(c->fps_slots, 0, sizeof(unsigned long long) * FPS_MAX_CLOUDS * 2 * FPS_MAX_G * 5, s));
-    static int hog = -1;
-    if (hog < 0) { const char* e = getenv("BX_FPS_HOG"); hog = e ? atoi(e) : 0; }
-    size_t lds = 0;
-    if (hog > 0 && (j0 > 0 || j1 < m)) {
-        lds = (size_t)hog * 1024;
-        static bool attr = false;
-        if (!attr) {
-            BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-            BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-            BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-            attr = true;
-        }
+    // XCD co-location: every cloud's workgroups on one XCD (32 CUs each), the two clouds of a pair on different XCDs; the pair of
+    // XCDs rotates from launch to launch so that contexts working side by side do not queue on the same CUs
+    const char* ec = getenv("BX_FPS_COLOCATE");     // test hook: 0 = dispatch-order placement (agent-scope protocol)
+    const int coloc = ec ? atoi(ec) : 1;
+    int gmax = 0;
+    for (int i = 0; i < nclouds; ++i) gmax = a.G[i] > gmax ? a.G[i] : gmax;
+    a.colocate = (coloc && gmax > 1 && gmax <= 32) ? 1 : 0;
+    a.hello = c->fps_hello;
+    if (a.colocate) {
+        if (j0 == 0) c->fps_rot = (c->fps_rot + 1) & 3;         // the launches of one tiled run keep their XCDs (not required, tidy)
+        for (int i = 0; i < nclouds; ++i) a.xcd[i] = (2 * c->fps_rot + i) & 7;
+        BX_HIP(hipMemsetAsync(c->fps_hello, 0, sizeof(unsigned long long) * FPS_MAX_CLOUDS * FPS_MAX_G, s));
+        total = 8 * gmax;
     }
+    // epochs continue across the launches of a tiled run: the slots are cleared once, in front of the first one
+    if (j0 == 0) BX_HIP(hipMemsetAsync(c->fps_slots, 0, sizeof(unsigned long long) * FPS_MAX_CLOUDS * 2 * FPS_MAX_G * FPS_REC, s));
+    const size_t lds = 0;
     if (ppt == 4) hipLaunchKernelGGL(fps_kernel<4>, dim3(total), dim3(FPS_THREADS), lds, s, a);
     else if (ppt == 8) hipLaunchKernelGGL(fps_kernel<8>, dim3(total), dim3(FPS_THREADS), lds, s, a);
     else hipLaunchKernelGGL(fps_kernel<16>, dim3(total), dim3(FPS_THREADS), lds, s, a);

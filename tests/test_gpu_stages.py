@@ -41,6 +41,35 @@ def test_fps_exact(ctx, oracle, n, m):
     assert np.array_equal(_np(kp), xyz[ref])
 
 
+@pytest.mark.parametrize("colocate", ["0", "1"])
+@pytest.mark.parametrize("ppt", ["4", "8", "16"])
+def test_fps_protocols_and_tilings(ctx, oracle, monkeypatch, colocate, ppt):
+    """Both exchange protocols (XCD co-located L2 granules / agent-scope granules in dispatch-order placement) and every
+    points-per-thread instantiation give the oracle's indices, ties included (BX_FPS_COLOCATE / BX_FPS_PPT are test hooks)."""
+    monkeypatch.setenv("BX_FPS_COLOCATE", colocate)
+    monkeypatch.setenv("BX_FPS_PPT", ppt)
+    rng = np.random.default_rng(7)
+    xyz = (rng.random((40000, 3), np.float32) * 4 - 1).astype(np.float32)
+    xyz[1000:3000] = np.round(xyz[1000:3000] * 2) / 2          # a lattice block: exact distance ties across workgroups
+    idx, kp = ctx.fps(xyz, 300)
+    ref = oracle.fps(xyz, 300)
+    assert np.array_equal(_np(idx), ref)
+    assert np.array_equal(_np(kp), xyz[ref])
+
+
+def test_fps_beyond_one_xcd(bx, oracle, packed):
+    """More than 32 workgroups per cloud cannot share one XCD: dispatch-order placement, agent-scope protocol (600k points)."""
+    from bufferx_amd import lib
+    rng = np.random.default_rng(600)
+    xyz = (rng.random((600000, 3), np.float32) * 50).astype(np.float32)
+    c = lib.Context(_cfg(bx, K=64, P=64, S=1, nk=64), max_points=600000, device=0, packed_weights=packed)
+    try:
+        idx, _ = c.fps(xyz, 40)
+        assert np.array_equal(_np(idx), oracle.fps(xyz, 40))
+    finally:
+        c.close()
+
+
 def test_fps_ties_and_origin_skip(ctx, oracle):
     # integer lattice => many exact distance ties (tie rule: lower k mod 512, then lower k);
     # points within 1e-3 of the origin are never candidates (upstream `continue`)
