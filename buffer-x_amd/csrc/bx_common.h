@@ -146,6 +146,7 @@ struct bx_ctx {
     float* fps_dist;                    // [2][max_points]  (unused by register path; kept for generic path)
     unsigned long long* fps_slots;      // cross-workgroup exchange granules
     unsigned long long* fps_hello;      // [2][64] placement handshake granules (k_fps.hip)
+    int fps_attr_set;
     int fps_rot;                        // rotates the XCD pair the co-located FPS launches of this context aim at
     int32_t* ransac_inl;                // [RANSAC_BATCH]
     double* ransac_err;                 // [RANSAC_BATCH]

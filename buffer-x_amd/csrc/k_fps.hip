@@ -150,6 +150,11 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
     while (T * 2 <= n && T * 2 <= 512) { T *= 2; ++lt; }
     const unsigned tmask = (unsigned)(T - 1);
 
+    // PPT <= 8: the workgroup's coordinates also sit in LDS ([3][PPT * 1024] floats), so that the scan only tracks {distance, slot}
+    // and the coordinates of a winner are ONE LDS read by the lane that needs them (3 selects per point less in the VALU-bound scan)
+    constexpr bool LDSXYZ = PPT <= 8;
+    constexpr int NP = PPT * FPS_THREADS;
+    extern __shared__ float s_pts[];
     float px[PPT], py[PPT], pz[PPT], td[PPT];
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
@@ -164,7 +169,17 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
         } else {
             px[i] = 0.f; py[i] = 0.f; pz[i] = 0.f; td[i] = -1.0f;
         }
+        if (LDSXYZ) {
+            s_pts[i * FPS_THREADS + t] = px[i];
+            s_pts[NP + i * FPS_THREADS + t] = py[i];
+            s_pts[2 * NP + i * FPS_THREADS + t] = pz[i];
+        }
     }
+    // local slot (= k - base) of the point a key names
+    auto key_slot = [&](long long kk) -> int {
+        const unsigned tbw = ~(unsigned)((unsigned long long)kk & 0xffffffffu);
+        return (int)(((tbw & 0x7fffffu) << lt) | (tbw >> 23)) - base;
+    };
     float cx = xyz[0], cy = xyz[1], cz = xyz[2];
     if (a.j0 > 0) {   // the previous launch of this stream wrote the last keypoint (kernel boundary: visible)
         const float* lk = a.kpts_out[cloud] + (size_t)(a.j0 - 1) * 3;
@@ -221,9 +236,11 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
             bool better = d2 > bd;
             bd = better ? d2 : bd;
             bi = better ? i : bi;
-            bx = better ? px[i] : bx;
-            by = better ? py[i] : by;
-            bz = better ? pz[i] : bz;
+            if (!LDSXYZ) {
+                bx = better ? px[i] : bx;
+                by = better ? py[i] : by;
+                bz = better ? pz[i] : bz;
+            }
         }
         FPS_TR(1);
         unsigned k = (unsigned)(base + bi * FPS_THREADS + t);
@@ -233,7 +250,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
         const long long wk = wave_max_key(key);
         if (key == wk) {  // keys are unique per thread (they embed the point index)
             s_key[par][wave] = wk;
-            s_xyz[par][wave][0] = bx; s_xyz[par][wave][1] = by; s_xyz[par][wave][2] = bz;
+            if (!LDSXYZ) { s_xyz[par][wave][0] = bx; s_xyz[par][wave][1] = by; s_xyz[par][wave][2] = bz; }
         }
         FPS_TR(2);
         __syncthreads();
@@ -251,6 +268,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                 fy = b ? s_xyz[par][w][1] : fy;
                 fz = b ? s_xyz[par][w][2] : fz;
             }
+            if (LDSXYZ) { const int sl = key_slot(fk); fx = s_pts[sl]; fy = s_pts[NP + sl]; fz = s_pts[2 * NP + sl]; }
         } else {
             if (wave == 0) {
                 // combine the 16 wave records
@@ -261,8 +279,14 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                 int src = __ffsll((long long)bal) - 1;
                 unsigned long long* my = slots + ((size_t)par * FPS_MAX_G + g) * FPS_REC;
                 {   // lanes 0..4 store one granule each: one store instruction, one 40-byte write
-                    const unsigned sx = __float_as_uint(s_xyz[par][src][0]), sy = __float_as_uint(s_xyz[par][src][1]);
-                    const unsigned sz = __float_as_uint(s_xyz[par][src][2]);
+                    unsigned sx, sy, sz;
+                    if (LDSXYZ) {
+                        const int sl = key_slot(mk);
+                        sx = __float_as_uint(s_pts[sl]); sy = __float_as_uint(s_pts[NP + sl]); sz = __float_as_uint(s_pts[2 * NP + sl]);
+                    } else {
+                        sx = __float_as_uint(s_xyz[par][src][0]); sy = __float_as_uint(s_xyz[par][src][1]);
+                        sz = __float_as_uint(s_xyz[par][src][2]);
+                    }
                     const unsigned khi = (unsigned)((unsigned long long)mk >> 32), klo = (unsigned)((unsigned long long)mk & 0xffffffffu);
                     const unsigned v = lane == 0 ? khi : (lane == 1 ? klo : (lane == 2 ? sx : (lane == 3 ? sy : sz)));
                     if (lane < 5) granule_store(my + lane, ((unsigned long long)(unsigned)j << 32) | v, fast);
@@ -422,7 +446,11 @@ int bxk_fps_range(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* 
     }
     // epochs continue across the launches of a tiled run: the slots are cleared once, in front of the first one
     if (j0 == 0) BX_HIP(hipMemsetAsync(c->fps_slots, 0, sizeof(unsigned long long) * FPS_MAX_CLOUDS * 2 * FPS_MAX_G * FPS_REC, s));
-    const size_t lds = 0;
+    const size_t lds = ppt <= 8 ? (size_t)3 * ppt * FPS_THREADS * sizeof(float) : 0;     // PPT 8: 96 KiB
+    if (lds > 48 * 1024 && !c->fps_attr_set) {
+        BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        c->fps_attr_set = 1;
+    }
     if (ppt == 4) hipLaunchKernelGGL(fps_kernel<4>, dim3(total), dim3(FPS_THREADS), lds, s, a);
     else if (ppt == 8) hipLaunchKernelGGL(fps_kernel<8>, dim3(total), dim3(FPS_THREADS), lds, s, a);
     else hipLaunchKernelGGL(fps_kernel<16>, dim3(total), dim3(FPS_THREADS), lds, s, a);
