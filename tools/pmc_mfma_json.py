@@ -20,7 +20,7 @@ for f in sorted(glob.glob(os.path.join(root, "*.db"))):
         k = k[:k.find("(")] if "(" in k else k
         rows.setdefault(k, {})[ctr] = (n, v, d)
 
-out = {"source": root, "units": "busy = matrix-pipe busy share of elapsed shader cycles; clock_GHz = effective shader clock", "kernels": {}}
+out = {"source": os.path.relpath(root) if os.path.isabs(root) else root, "units": "busy = matrix-pipe busy share of elapsed shader cycles; clock_GHz = effective shader clock", "kernels": {}}
 for k, c in rows.items():
     g, m = c.get("GRBM_GUI_ACTIVE"), c.get("SQ_VALU_MFMA_BUSY_CYCLES")
     if not g or not m or m[1] <= 0:

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 TAG=${1:-r02}
 rm -rf $OUT/prof_$TAG && mkdir -p $OUT/prof_$TAG
-CMD="python bench.py --steps 4 --warmup 1 --inflight 1 --no-cpu-baseline"
+CMD="python bench.py --steps 4 --warmup 1 --inflight 1 --no-cpu-baseline --latency-tiles 0"
 # (1) kernel trace + stats (1 pair in flight so kernel durations are not inflated by overlap)
 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG/kt -o kt -- $CMD > $OUT/prof_$TAG/bench_kt.log 2>&1
 # (2) PMC passes, each in its own run (FETCH_SIZE and WRITE_SIZE cannot share a pass)
