@@ -41,4 +41,6 @@ def test_world2_records_equal_world1(tmp_path):
         assert j["n_gpus"] == n and j["unit"] == "pairs/s" and j["value"] > 0 and j["scaling"] == "weak"
         assert j["roofline"]["bound"] == "mfma" and j["roofline_neighbour_gather"]["bound"] == "hbm"
         assert set(j["work"]) >= {"mean_m_per_scale", "mean_M", "mean_C", "mean_ransac_iters"}
+        lf = j["p50_ms_per_pair_latency_form"]
+        assert lf["results_identical_to_throughput_form"] is True and lf["p50_ms"] > 0 and j["p50_ms_per_pair_inflight1"] > 0
     assert j1["registered_ok"] == j2["registered_ok"] == j3["registered_ok"]
