@@ -1,6 +1,7 @@
 // bx_api.hip -- C-ABI of libbufferx_hip.so (include/bufferx.h): context, weights, stage entry points and
 // the whole-pair pipeline (reference BufferX.forward inference branch, models/BUFFERX.py:257-467).
 #include "bx_common.h"
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -38,6 +39,11 @@ struct ProfScope {
 };
 
 }  // namespace
+
+// contexts alive per device (this process): the FPS launcher sizes its XCD co-location by it (k_fps.hip)
+static std::atomic<int> g_live[64];
+static std::atomic<int> g_created[64];
+int bx_live_contexts(int device) { return device >= 0 && device < 64 ? g_live[device].load() : 1 << 20; }
 
 // event bracket usable from the other translation units (tag 12 = the neighbour-gather query kernel alone)
 void bx_prof_mark(bx_ctx* c, hipStream_t s, int tag, int begin)
@@ -434,6 +440,7 @@ int bx_create(int device_id, const bx_params* params, bx_ctx** out)
     memset(c, 0, sizeof(*c));
     c->device = device_id;
     c->p = p;
+    if (device_id < 64) { c->fps_xcd_pair = g_created[device_id].fetch_add(1) & 3; g_live[device_id].fetch_add(1); }
     const int rc = create_impl(c, device_id);
     if (rc != BX_OK) {
         // bx_destroy releases whatever had been allocated; it must not clobber the message of the failure
@@ -452,6 +459,7 @@ int bx_destroy(bx_ctx* c)
     if (!c) return BX_OK;
     BxDevScope ds(c->device);
     (void)hipDeviceSynchronize();
+    if (c->device >= 0 && c->device < 64) g_live[c->device].fetch_sub(1);
     bxk_pre_release(c);
     if (c->prof) {
         auto* v = static_cast<std::vector<ProfEvt>*>(c->prof);

@@ -147,7 +147,7 @@ struct bx_ctx {
     unsigned long long* fps_slots;      // cross-workgroup exchange granules
     unsigned long long* fps_hello;      // [2][64] placement handshake granules (k_fps.hip)
     int fps_attr_set;
-    int fps_rot;                        // rotates the XCD pair the co-located FPS launches of this context aim at
+    int fps_xcd_pair;                   // 0..3: the XCD pair {2p, 2p+1} the co-located FPS launches of this context aim at (creation order mod 4)
     int32_t* ransac_inl;                // [RANSAC_BATCH]
     double* ransac_err;                 // [RANSAC_BATCH]
     double* ransac_T;                   // [RANSAC_BATCH][12]
@@ -193,6 +193,7 @@ constexpr int BX_RANSAC_BATCH = 4096;
 // ------------------------------------------------------------------ kernel launchers (one per .hip file)
 int bxk_fps(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* n, int nclouds, int m, int32_t* const* idx_out,
             float* const* kpts_out);
+int bx_live_contexts(int device);   // contexts alive on the device in this process (bx_api.hip)
 int bxk_fps_range(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* n, int nclouds, int j0, int j1, int m,
                   int32_t* const* idx_out, float* const* kpts_out);
 int bxk_gather_rows(hipStream_t s, const float* pts, const int32_t* idx, int n, float* out);

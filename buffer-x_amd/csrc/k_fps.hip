@@ -430,17 +430,19 @@ int bxk_fps_range(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* 
         total += a.G[i];
     }
     a.wg_start[nclouds] = total;
-    // XCD co-location: every cloud's workgroups on one XCD (32 CUs each), the two clouds of a pair on different XCDs; the pair of
-    // XCDs rotates from launch to launch so that contexts working side by side do not queue on the same CUs
+    // XCD co-location: every cloud's workgroups on one XCD (32 CUs each), the two clouds of a pair on the two XCDs of the context's
+    // pair; contexts take the four pairs in creation order.  The workgroups of a cloud wait for each other, so everything aimed at
+    // one XCD must be able to be resident there at once whatever the other contexts launch: co-locate only while
+    // G x (contexts sharing the XCD) <= 32 workgroups -- otherwise dispatch-order placement over the whole chip, as before.
     const char* ec = getenv("BX_FPS_COLOCATE");     // test hook: 0 = dispatch-order placement (agent-scope protocol)
     const int coloc = ec ? atoi(ec) : 1;
     int gmax = 0;
     for (int i = 0; i < nclouds; ++i) gmax = a.G[i] > gmax ? a.G[i] : gmax;
-    a.colocate = (coloc && gmax > 1 && gmax <= 32) ? 1 : 0;
+    const int sharing = (bx_live_contexts(c->device) + 3) / 4;
+    a.colocate = (coloc && gmax > 1 && gmax * (sharing < 1 ? 1 : sharing) <= 32) ? 1 : 0;
     a.hello = c->fps_hello;
     if (a.colocate) {
-        if (j0 == 0) c->fps_rot = (c->fps_rot + 1) & 3;         // the launches of one tiled run keep their XCDs (not required, tidy)
-        for (int i = 0; i < nclouds; ++i) a.xcd[i] = (2 * c->fps_rot + i) & 7;
+        for (int i = 0; i < nclouds; ++i) a.xcd[i] = (2 * c->fps_xcd_pair + i) & 7;
         BX_HIP(hipMemsetAsync(c->fps_hello, 0, sizeof(unsigned long long) * FPS_MAX_CLOUDS * FPS_MAX_G, s));
         total = 8 * gmax;
     }
