@@ -838,8 +838,10 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
         }
     }
     if (T == 1) tb[1] = KM;
-    const bool tiled = T > 1;
-    if (tiled && c->cap_on) { bx_set_error("bx_register_pair: bx_set_capture needs keypoint_tiles <= 1"); return BX_ERR_STATE; }
+    const bool tiled = T > 1;                       // FPS in several launches on the context's own stream
+    const bool multi = p.keypoint_tiles > 1;        // source / target / matching chains on the context's streams (also when K <= nk
+                                                    // leaves nothing to tile: the reference's default num_fps = 1500 < 2000)
+    if (multi && c->cap_on) { bx_set_error("bx_register_pair: bx_set_capture needs keypoint_tiles <= 1"); return BX_ERR_STATE; }
     hipStream_t fs = tiled ? c->aux_stream : s;
     if (tiled) {
         BX_HIP(hipEventRecord(c->ev_fork, s));
@@ -874,7 +876,7 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
     // chain's launch is filled by the other's (the same overlap several pairs in flight give the throughput form).
     auto describe = [&](int i, int cl, int k0, int kn) -> int {
         const bool capc = c->cap_on && c->cap.scale == i && c->cap.cloud == cl;
-        const bool side = tiled && cl == 1;
+        const bool side = multi && cl == 1;
         hipStream_t ds = side ? c->tgt_stream : s;
         float* patches = side ? c->patches2 : c->patches;
         float* feat = side ? c->feat2 : c->feat;
@@ -891,7 +893,7 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
             if ((rc = cap_copy(ds, c->cap.patches, patches, (size_t)K * P * 3)) != BX_OK) return rc;
             if ((rc = cap_copy(ds, c->cap.feat, feat, (size_t)K * BX_RAD * BX_EA * 16)) != BX_OK) return rc;
         }
-        if (tiled) {
+        if (multi) {
             ProfScope ps(c, ds, 4);
             if ((rc = desc_stack(c, ds, feat, kn, c->desc_sc[i][cl] + (size_t)k0 * 32, c->equi_sc[i][cl] + (size_t)k0 * BX_EA * 32, nullptr, side ? c->act2 : c->act3)) != BX_OK) return rc;
             if (k0 + kn == K) BX_HIP(hipEventRecord(c->ev_desc[cl][i], ds));     // this (cloud, scale) is complete
@@ -903,13 +905,13 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
     };
     // the target chain starts behind whatever the caller's stream has enqueued so far / the caller's stream waits for it
     auto tgt_go = [&]() -> int {
-        if (!tiled) return BX_OK;
+        if (!multi) return BX_OK;
         BX_HIP(hipEventRecord(c->ev_tgt_go, s));
         BX_HIP(hipStreamWaitEvent(c->tgt_stream, c->ev_tgt_go, 0));
         return BX_OK;
     };
     auto tgt_join = [&]() -> int {
-        if (!tiled) return BX_OK;
+        if (!multi) return BX_OK;
         BX_HIP(hipEventRecord(c->ev_tgt_done, c->tgt_stream));
         BX_HIP(hipStreamWaitEvent(s, c->ev_tgt_done, 0));
         return BX_OK;
@@ -921,7 +923,7 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
         const int k0 = tb[t], kn = (t == T - 1 ? K : tb[t + 1]) - k0;
         if (tiled && t > 0) BX_HIP(hipStreamWaitEvent(s, c->ev_tile[t], 0));
         { ProfScope ps(c, s, 13); if ((rc = bxk_ball_rows(c, s, c->kpts, 2, S, k0, kn)) != BX_OK) return rc; }
-        if (!tiled) break;
+        if (!multi) break;
         if ((rc = tgt_go()) != BX_OK) return rc;
         for (int i = 0; i < (early ? 1 : S); ++i)
             for (int cl = 0; cl < 2; ++cl)
@@ -930,7 +932,7 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
     // no early exit: nothing of a scale's matching decides what the later scales do -- it runs on the third stream, beside the
     // descriptor work still queued on the other two, and only the last scale's matching is exposed
     hipStream_t s_caller = s;
-    const bool split_match = tiled && !early;
+    const bool split_match = multi && !early;
     if (!split_match) { if ((rc = tgt_join()) != BX_OK) return rc; }
     int ransac_calls = 0;
     if (split_match) s = c->match_stream;
@@ -941,7 +943,7 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
         }
         c->skip = (early && i > 0) ? &st->done : nullptr;
         const bool capi = c->cap_on && c->cap.scale == i;
-        if (!tiled || (early && i > 0)) {
+        if (!multi || (early && i > 0)) {
             if ((rc = tgt_go()) != BX_OK) return rc;
             for (int cl = 0; cl < 2; ++cl)
                 if ((rc = describe(i, cl, 0, K)) != BX_OK) return rc;

@@ -50,6 +50,29 @@ def test_tiled_pair_equals_untiled(bx, packed, tiles, mode):
     assert out[0][4] == (1 if mode == "taken" else S)
 
 
+@pytest.mark.parametrize("early", [False, True])
+def test_streams_without_tiles(bx, packed, early):
+    """num_fps <= num_points_radius_estimate (the reference's default 1500 < 2000) leaves nothing to tile: the latency form still
+    runs the source / target / matching chains on the context's streams and must return the same result."""
+    from bufferx_amd import lib
+    K, P, S, nk = 200, 96, 2, 256
+    cfg = _cfg(bx, K, P, S, [5, 1], nk, early)
+    cfg.match.early_exit_min_inliers = 10 ** 6
+    pair = bx.synth.make_pair(6, "indoor", n_target=9000, shared=True)
+    ns, nt = len(pair["src"]), len(pair["tgt"])
+    rng = np.random.default_rng(3)
+    ps = np.stack([rng.permutation(ns) for _ in range(S)]).astype(np.int32)
+    pt = np.stack([rng.permutation(nt) for _ in range(S)]).astype(np.int32)
+    out = []
+    for t in (0, 2):
+        c = copy.deepcopy(cfg)
+        c.test.keypoint_tiles = t
+        ctx = lib.Context(c, max_points=max(ns, nt), device=0, packed_weights=packed)
+        out.append(_fields(ctx.register_pair(pair["src"], pair["tgt"], pair["aligned_z"], ps, pt, 12)))
+        ctx.close()
+    assert out[0] == out[1] and out[0][2] > 0 and out[0][4] == S
+
+
 def test_tiled_pair_equals_oracle(bx, packed, oracle):
     """The latency form against the CPU oracle pipeline directly (not only against the other GPU form)."""
     from bufferx_amd import lib
