@@ -409,10 +409,9 @@ int bxk_fps_range(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* 
     int nmax = 0;
     for (int i = 0; i < nclouds; ++i) nmax = n[i] > nmax ? n[i] : nmax;
     // points per thread: the per-iteration scan is VALU-bound (4 waves per SIMD), the all-to-all exchange grows by ~0.1 us per
-    // workgroup -- measured optimum: the smallest PPT that keeps a cloud within 8 workgroups (K = 5000: 2.0 / 2.2 / 2.3 us per
-    // iteration at 25k / 38k / 55k points)
-    if ((nmax + FPS_THREADS * 16 - 1) / (FPS_THREADS * 16) > FPS_MAX_G) { bx_set_error("bxk_fps: cloud of %d points exceeds %d", nmax, FPS_MAX_G * FPS_THREADS * 16); return BX_ERR_ARG; }
-    ppt = nmax <= 8 * FPS_THREADS * 4 ? 4 : (nmax <= 8 * FPS_THREADS * 8 ? 8 : 16);
+    // workgroup.  Measured (K = 5000): PPT 4 wins up to 8 workgroups (32k points: 1.8 us per iteration), PPT 8 with its LDS copy of
+    // the coordinates up to 16 workgroups (2.0 / 2.1 / 2.55 us at 38k / 55k / 100k points; PPT 16 at 100k: 3.2 us), PPT 16 beyond
+    ppt = nmax <= 8 * FPS_THREADS * 4 ? 4 : (nmax <= 16 * FPS_THREADS * 8 ? 8 : 16);
     {
         const char* e = getenv("BX_FPS_PPT");       // test hook: every PPT instantiation on any cloud size
         const int force = e ? atoi(e) : 0;

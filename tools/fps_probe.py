@@ -9,7 +9,7 @@ m = 5000
 cfg = bx.make_cfg("3DMatch"); cfg.patch.num_fps = m
 pw = bx.weights.fold_and_pack(bx.weights.synthetic_state_dict(0))
 for n in [int(a) for a in sys.argv[1:]] or [38000]:
-    pair = bx.synth.make_pair(100, "indoor", n_target=n, shared=True)
+    pair = bx.synth.make_pair(100, os.environ.get("KIND", "indoor"), n_target=n, shared=os.environ.get("KIND", "indoor") == "indoor")
     ctx = lib.Context(cfg, max_points=max(len(pair["src"]), len(pair["tgt"])), device=0, packed_weights=pw)
     S = cfg.patch.num_scales
     ns, nt = len(pair["src"]), len(pair["tgt"])
