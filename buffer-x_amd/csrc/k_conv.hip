@@ -100,6 +100,7 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave % C::WN, wm = wave / C::WN;
+    const int wm_u = __builtin_amdgcn_readfirstlane(wm);     // SGPR copy: branches on it are scalar
     const int li = lane & 15, kk = lane >> 4;
 
     // ---- both slab buffers start as zeros (the halo rows stay zero for the whole kernel)
@@ -224,12 +225,16 @@ __global__ __launch_bounds__(NW * 64, (ConvCfg<NCHUNK, NTAPS, P_IN, P_LDS, P_OUT
             for (int t = 0; t < C::TPW; ++t) {
                 if (t + 2 < C::TPW) a[t + 2 < C::TPW ? t + 2 : 0] = *reinterpret_cast<const f32x4*>(ab[t + 2 < C::TPW ? t + 2 : 0] + tb);
                 __builtin_amdgcn_sched_barrier(0);
+                // the last tile slot of a wave may lie beyond the map (MT not a multiple of WM: the 32-channel layers waste 2 of 20
+                // slots): a wave-uniform branch skips its MFMAs, the matrix pipe goes to the co-resident waves instead
+                if (C::MT % C::WM == 0 || t + 1 < C::TPW || wm_u + t * C::WM < C::MT) {
 #pragma unroll
-                for (int j = 0; j < NPW; ++j) {
-                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, b_[j][0], acc[t][j], 0, 0, 0);
-                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, b_[j][1], acc[t][j], 0, 0, 0);
-                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, b_[j][2], acc[t][j], 0, 0, 0);
-                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, b_[j][3], acc[t][j], 0, 0, 0);
+                    for (int j = 0; j < NPW; ++j) {
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, b_[j][0], acc[t][j], 0, 0, 0);
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, b_[j][1], acc[t][j], 0, 0, 0);
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, b_[j][2], acc[t][j], 0, 0, 0);
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, b_[j][3], acc[t][j], 0, 0, 0);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -393,6 +398,7 @@ __global__ __launch_bounds__(CT, 3) void cost_l1_kernel(const float* __restrict_
     const int u = blockIdx.x;
     if (u >= m) return;
     const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
+    const int wm_u = __builtin_amdgcn_readfirstlane(wm);
     const int li = lane & 15, kk = lane >> 4;
 
     const float* sp = s_equi + ((size_t)s_mids[u] * BX_EA + BX_AZI) * 32;  // elevation rows 1..5
@@ -447,6 +453,7 @@ __global__ __launch_bounds__(CT, 3) void cost_l1_kernel(const float* __restrict_
                 const int offT = (b * CV_W + c) * ROWB + cc * 64;
 #pragma unroll
                 for (int t = 0; t < TPW; ++t) {
+                    if (t + 1 == TPW && wm_u + t * WM >= MT) continue;   // tile slot beyond the 61 row tiles (waves 5..7): scalar branch
                     const f32x4 sv = *reinterpret_cast<const f32x4*>(cS + bS[t] + offS);
                     const f32x4 tv = *reinterpret_cast<const f32x4*>(cT + bT[t] + offT);
                     const f32x4 av = sv - tv;
