@@ -369,6 +369,14 @@ def main():
             "roofline": roof, "roofline_costnet": roof_cn, "roofline_neighbour_gather": roof_ng,
             "stages_ms_per_pair": {k: round(v[0] / NPROF, 3) for k, v in stages.items() if v[1]},
         }
+        # FPS is bound by its K strictly dependent iterations, not by HBM: report the latency per iteration and the
+        # point-update rate (both clouds of a pair run in one launch)
+        fps_ms, fps_n = stages.get("fps", (0.0, 0))
+        if fps_n:
+            it = max(K, cfg.patch.num_points_radius_estimate)
+            out["fps"] = {"bound": "dependent-iteration latency", "ms_per_pair": round(fps_ms / fps_n, 3), "iterations": it,
+                          "us_per_iteration": round(fps_ms / fps_n / it * 1e3, 3),
+                          "point_updates_per_s": round(it * 2.0 * nmean / (fps_ms / fps_n * 1e-3), 0)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["cpu_baseline_neighbour"] = cpu_baseline(bx, pw, pairs[0], cfg, stages, NPROF)
         print(json.dumps(out))
