@@ -380,7 +380,7 @@ constexpr int CV_ROWF = 36;                                           // 32 + 4 
 // costs two ds_read_b128 (immediate offsets), four v_sub and -- a wave owns both 16-channel column tiles -- EIGHT MFMAs.
 constexpr int CV_WE = CV_W + 4;                                       // 24 columns of the wrapped S map
 
-__global__ __launch_bounds__(CT, 3) void cost_l1_kernel(const float* __restrict__ s_equi, const float* __restrict__ t_equi,
+__global__ __launch_bounds__(CT, 2) void cost_l1_kernel(const float* __restrict__ s_equi, const float* __restrict__ t_equi,
                                                         const int32_t* __restrict__ s_mids, const int32_t* __restrict__ t_mids,
                                                         const int32_t* __restrict__ m_dev, int max_m, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ out, const int32_t* __restrict__ skip)
@@ -437,6 +437,12 @@ __global__ __launch_bounds__(CT, 3) void cost_l1_kernel(const float* __restrict_
     const char* cT = reinterpret_cast<const char*>(sT);
     const float4* w4 = reinterpret_cast<const float4*>(W) + lane;
     float4 bq0 = w4[0], bq1 = w4[64];
+    // Software pipeline over (tap, tile): the S / T rows of the NEXT tile are requested before the 8 MFMAs of the current one, so
+    // the wave never sits on an LDS round trip between two MFMA groups (one workgroup = 2 waves per SIMD is all the registers
+    // admit: a wave has to cover its own latencies).  Round 1 read the rows right in front of their MFMAs, into the
+    // accumulator's scratch registers (s_nop 7 + lgkmcnt(0) per tile): 73.5 % matrix-pipe occupancy.
+    f32x4 psv = *reinterpret_cast<const f32x4*>(cS + bS[0]);
+    f32x4 ptv = *reinterpret_cast<const f32x4*>(cT + bT[0]);
 #pragma unroll 1
     for (int cc = 0; cc < 2; ++cc) {
 #pragma unroll 1
@@ -453,15 +459,30 @@ __global__ __launch_bounds__(CT, 3) void cost_l1_kernel(const float* __restrict_
                 const int offT = (b * CV_W + c) * ROWB + cc * 64;
 #pragma unroll
                 for (int t = 0; t < TPW; ++t) {
+                    const f32x4 av = psv - ptv;
+                    // operands of the tile after this one: next tile of the tap, or tile 0 of the next tap (next a: the S column
+                    // moves one to the left; next chunk: back to the first column, channels 16..31)
+                    if (t + 1 < TPW) {
+                        psv = *reinterpret_cast<const f32x4*>(cS + bS[t + 1 < TPW ? t + 1 : 0] + offS);
+                        ptv = *reinterpret_cast<const f32x4*>(cT + bT[t + 1 < TPW ? t + 1 : 0] + offT);
+                    } else if (bc < 8) {
+                        constexpr int dummy = 0; (void)dummy;
+                        const int nb = (bc + 1) / 3, nc = (bc + 1) % 3;
+                        psv = *reinterpret_cast<const f32x4*>(cS + bS[0] + (nb * CV_WE + nc) * ROWB + cc * 64);
+                        ptv = *reinterpret_cast<const f32x4*>(cT + bT[0] + (nb * CV_W + nc) * ROWB + cc * 64);
+                    } else {
+                        const int ncc = a < 2 ? cc : (cc + 1) & 1;                 // after the last tap: wraps to the start (unused)
+                        const int sh = a < 2 ? -ROWB : 2 * ROWB;
+                        psv = *reinterpret_cast<const f32x4*>(cS + bS[0] + sh + ncc * 64);
+                        ptv = *reinterpret_cast<const f32x4*>(cT + bT[0] + ncc * 64);
+                    }
                     if (t + 1 == TPW && wm_u + t * WM >= MT) continue;   // tile slot beyond the 61 row tiles (waves 5..7): scalar branch
-                    const f32x4 sv = *reinterpret_cast<const f32x4*>(cS + bS[t] + offS);
-                    const f32x4 tv = *reinterpret_cast<const f32x4*>(cT + bT[t] + offT);
-                    const f32x4 av = sv - tv;
                     __builtin_amdgcn_sched_barrier(0);
                     acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bq0.x, acc[t][0], 0, 0, 0);
                     acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bq0.y, acc[t][0], 0, 0, 0);
                     acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bq0.z, acc[t][0], 0, 0, 0);
                     acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bq0.w, acc[t][0], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);       // two dependent chains back to back, not interleaved (ubench: 153 vs 124 TF)
                     acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bq1.x, acc[t][1], 0, 0, 0);
                     acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bq1.y, acc[t][1], 0, 0, 0);
                     acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bq1.z, acc[t][1], 0, 0, 0);
