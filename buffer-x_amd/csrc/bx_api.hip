@@ -495,6 +495,24 @@ int bx_debug_read(bx_ctx* c, int64_t* out, int32_t n)
     return BX_OK;
 }
 
+int bx_keypoint_tile_bounds(const bx_params* params, int32_t* bounds)
+{
+    if (!params || !bounds) { bx_set_error("bx_keypoint_tile_bounds: null argument"); return 0; }
+    const int K = params->num_fps, NK = params->num_points_radius_estimate, want = params->keypoint_tiles;
+    for (int i = 0; i <= BX_MAX_TILES; ++i) bounds[i] = 0;
+    int T = 1;
+    if (want > 1 && want <= BX_MAX_TILES && K > NK + 4) {
+        const int first = (NK + 3) & ~3;
+        bounds[1] = first;
+        for (int t = 2; t <= want; ++t) {
+            const int e = t == want ? K : first + (int)((int64_t)(K - first) * (t - 1) / (want - 1)) / 4 * 4;
+            if (e > bounds[T]) bounds[++T] = e;
+        }
+    }
+    if (T == 1) bounds[1] = K > 0 ? K : 0;
+    return T;
+}
+
 int bx_set_capture(bx_ctx* c, const bx_capture* cap)
 {
     if (!c) { bx_set_error("null context"); return BX_ERR_ARG; }
@@ -827,17 +845,9 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
     const float* clouds[2] = {src, tgt};
     const int ns[2] = {n_src, n_tgt};
     const int32_t* perms[2] = {perm_src, perm_tgt};
-    int tb[BX_MAX_TILES + 1] = {0};
-    int T = 1;
-    if (p.keypoint_tiles > 1 && K > NK + 4) {
-        const int first = (NK + 3) & ~3;
-        tb[1] = first;
-        for (int t = 2; t <= p.keypoint_tiles; ++t) {
-            int e = t == p.keypoint_tiles ? K : first + (int)((int64_t)(K - first) * (t - 1) / (p.keypoint_tiles - 1)) / 4 * 4;
-            if (e > tb[T]) tb[++T] = e;
-        }
-    }
-    if (T == 1) tb[1] = KM;
+    int32_t tb[BX_MAX_TILES + 1] = {0};
+    const int T = bx_keypoint_tile_bounds(&p, tb);
+    if (T == 1) tb[1] = KM;                       // one launch covers the radius-estimation prefix too
     const bool tiled = T > 1;                       // FPS in several launches on the context's own stream
     const bool multi = p.keypoint_tiles > 1;        // source / target / matching chains on the context's streams (also when K <= nk
                                                     // leaves nothing to tile: the reference's default num_fps = 1500 < 2000)

@@ -52,7 +52,7 @@ class BxCapture(C.Structure):
 
 
 EXPORTS = ["bx_create", "bx_destroy", "bx_last_error", "bx_load_weights", "bx_workspace_bytes", "bx_register_pair",
-           "bx_set_capture",
+           "bx_set_capture", "bx_keypoint_tile_bounds",
            "bx_profile_enable", "bx_profile_read", "bx_debug_read",
            "bx_fps", "bx_radius", "bx_permute", "bx_ball_group", "bx_patch_features", "bx_desc_net", "bx_conv_layer",
            "bx_mutual", "bx_pose_net", "bx_hypotheses", "bx_consensus", "bx_ransac", "bx_kiss_solve", "bx_refine",

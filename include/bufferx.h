@@ -168,6 +168,12 @@ typedef struct bx_capture {
 } bx_capture;
 int bx_set_capture(bx_ctx *ctx, const bx_capture *cap);
 
+/* Keypoint tiles of the latency form (bx_params.keypoint_tiles): writes the T + 1 tile boundaries 0 = b[0] < ... < b[T] into
+ * bounds[BX_MAX_TILES + 1] and returns T (1 = not tiled: keypoint_tiles <= 1, or num_fps <= num_points_radius_estimate + 4).
+ * Tile 0 ends at num_points_radius_estimate rounded up to a multiple of 4 (the radius estimation needs exactly those keypoints);
+ * the rest is split evenly in multiples of 4.  Pure host arithmetic (no device call): what bx_register_pair uses. */
+int bx_keypoint_tile_bounds(const bx_params *params, int32_t *bounds);
+
 /* ---- stage entry points (parity tests + operator-level drop-ins) ----------------------------- */
 
 /* pointnet2_ops.furthest_point_sample + gather_operation (models/BUFFERX.py:286-290,338-346).

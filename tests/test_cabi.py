@@ -33,6 +33,36 @@ def test_struct_layouts_match_header():
     assert lib.BxParams.delta.offset == 32 and lib.BxParams.confidence.offset == 32 + 8 * 12
 
 
+def test_keypoint_tile_bounds():
+    """bx_keypoint_tile_bounds (pure host arithmetic of the latency form): tile 0 ends at the radius-estimation prefix rounded up
+    to 4, the rest is split evenly in multiples of 4, empty tiles collapse, K <= nk + 4 is not tiled."""
+    import bufferx_amd
+    from bufferx_amd import lib
+    so = lib.load()
+    so.bx_keypoint_tile_bounds.restype = C.c_int
+    b = (C.c_int32 * 9)()
+
+    def bounds(K, nk, tiles):
+        cfg = bufferx_amd.make_cfg("3DMatch")
+        cfg.patch.num_fps, cfg.patch.num_points_radius_estimate = K, nk
+        cfg.test.keypoint_tiles = tiles
+        p = lib.params_from_cfg(cfg, 1000)
+        T = so.bx_keypoint_tile_bounds(C.byref(p), b)
+        return T, list(b[:T + 1])
+
+    assert bounds(5000, 2000, 0) == (1, [0, 5000])
+    assert bounds(5000, 2000, 2) == (2, [0, 2000, 5000])
+    assert bounds(5000, 2000, 3) == (3, [0, 2000, 3500, 5000])
+    assert bounds(5000, 2000, 5) == (5, [0, 2000, 2748, 3500, 4248, 5000])
+    assert bounds(400, 96, 3) == (3, [0, 96, 248, 400])
+    assert bounds(1500, 2000, 4) == (1, [0, 1500])          # reference default: nothing to tile
+    assert bounds(2004, 2000, 4) == (1, [0, 2004])
+    T, bb = bounds(2010, 1998, 8)
+    assert bb[0] == 0 and bb[-1] == 2010 and all(x < y for x, y in zip(bb, bb[1:])) and bb[1] == 2000
+    T, bb = bounds(4999, 2001, 4)
+    assert bb[1] == 2004 and bb[-1] == 4999 and all((x % 4) == 0 for x in bb[:-1])
+
+
 def test_error_path_without_gpu():
     """bx_create on a box without a GPU must return an error code and a message, never abort."""
     import torch
