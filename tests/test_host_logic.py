@@ -148,3 +148,33 @@ def test_neighbour_sets_match_reference_nanoflann(oracle, bx):
         k = min(P, cnt[i])
         assert np.array_equal(idx[i, :k], s[:k])
         assert (idx[i, k:] == idx[i, 0]).all()
+
+
+def test_bench_workloads_generate_valid_pairs(bx):
+    """bench.py's synthetic workloads (BASELINE configs[1..4]) on CPU: every generator returns finite float32 clouds, a rigid ground
+    truth, per-scale permutations that are permutations, and is deterministic in its seed (every rank builds the same pair list)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert set(bench.WORKLOADS) >= {"3dmatch", "3dlomatch", "3dmatch-noisy", "kitti", "tiers"}
+    for wl in ("3dmatch", "3dlomatch", "kitti", "tiers"):
+        a = bench.make_inputs(bx, 1, 100, 3, wl)[0]
+        b = bench.make_inputs(bx, 1, 100, 3, wl)[0]
+        for k in ("src", "tgt"):
+            assert a[k].dtype == np.float32 and a[k].ndim == 2 and a[k].shape[1] == 3 and np.isfinite(a[k]).all()
+            assert np.array_equal(a[k], b[k])
+        T = np.asarray(a["T_gt"], np.float64)
+        R = T[:3, :3]
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-6) and abs(np.linalg.det(R) - 1.0) < 1e-6
+        for k, n in (("perm_src", len(a["src"])), ("perm_tgt", len(a["tgt"]))):
+            assert a[k].shape == (3, n) and a[k].dtype == np.int32
+            assert all(np.array_equal(np.sort(row), np.arange(n)) for row in a[k])
+            assert np.array_equal(a[k], b[k])
+    # the registering workload: the two fragments share surface samples inside the overlap (what lets random weights register it)
+    p = bench.make_inputs(bx, 1, 100, 3, "3dmatch")[0]
+    moved = (p["src"].astype(np.float64) @ np.asarray(p["T_gt"])[:3, :3].T + np.asarray(p["T_gt"])[:3, 3]).astype(np.float32)
+    from scipy.spatial import cKDTree
+    d, _ = cKDTree(p["tgt"]).query(moved)
+    assert (d < 1e-4).mean() > 0.3
