@@ -90,3 +90,16 @@ def test_slot_permutation_is_involution_free_bijection():
     ch = lib.logical_to_chunked(np.arange(16, dtype=np.float32)[None])[0]
     for c in range(16):
         assert ch[4 * (c % 4) + c // 4] == c
+
+
+def test_header_is_plain_c_and_cxx():
+    """include/bufferx.h is the drop-in boundary: it must compile on its own as C99 and as C++11 (no torch / HIP types in the
+    signatures), warnings as errors."""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "bufferx.h")
+    for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr],
+                ["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++", hdr]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    src = open(hdr).read()
+    assert "torch" not in src.lower() and "hip/" not in src and "at::" not in src
