@@ -194,6 +194,17 @@ def make_tiers_pair(seed):
     return dict(src=np.ascontiguousarray(src, np.float32), tgt=np.ascontiguousarray(tgt, np.float32), T_gt=T, aligned_z=True)
 
 
+def pose_difference(T_a, T_b):
+    """(rotation difference in degrees, translation difference in metres) of two NEARLY EQUAL poses, well-conditioned at zero:
+    angle = 2 asin(|R_a - R_b|_F / (2 sqrt 2)).  The reference's RRE (arccos of the trace, `pose_error` below) cannot resolve
+    differences below ~0.05 deg between float32 poses -- the trace of a float32 rotation carries ~1e-6 of rounding and
+    arccos(1 - 1e-6 / 2) = 0.04 deg -- so parity of two implementations' poses is measured with this instead."""
+    Ra, Rb = np.asarray(T_a, np.float64)[:3, :3], np.asarray(T_b, np.float64)[:3, :3]
+    fro = float(np.linalg.norm(Ra - Rb))
+    ang = 2.0 * np.degrees(np.arcsin(min(1.0, fro / (2.0 * np.sqrt(2.0)))))
+    return float(ang), float(np.linalg.norm(np.asarray(T_a, np.float64)[:3, 3] - np.asarray(T_b, np.float64)[:3, 3]))
+
+
 def pose_error(T_est, T_gt):
     """(RRE degrees, RTE metres), reference utils/SE3.py:134-165."""
     R = T_est[:3, :3] @ T_gt[:3, :3].T

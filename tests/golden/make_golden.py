@@ -32,6 +32,9 @@ CASES = {
     "outdoor_small": ("KITTI", "outdoor", 0, 5,
                       dict(num_fps=80, num_points_per_patch=64, num_scales=1, search_radius_thresholds=[2],
                            num_points_radius_estimate=200, iter_n=1200)),
+    # BASELINE configs[0]: 1 scale, 512 FPS keypoints, 512 points per patch, RANSAC + refinement, the config's own 2000 radius keypoints
+    "baseline_cfg0": ("3DMatch", "indoor_identical", 20000, 21,
+                      dict(num_fps=512, num_points_per_patch=512, num_scales=1, search_radius_thresholds=[5], iter_n=4000)),
 }
 
 
@@ -180,8 +183,10 @@ def helper_vectors():
 
 
 if __name__ == "__main__":
-    np.savez_compressed(os.path.join(HERE, "helpers.npz"), **helper_vectors())
-    for name in CASES:
+    only = sys.argv[1:]                      # optional: names of the cases to (re)mint; default = helpers + every case
+    if not only:
+        np.savez_compressed(os.path.join(HERE, "helpers.npz"), **helper_vectors())
+    for name in (only or CASES):
         cap = run_reference(name)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **cap)
         print(name, "pose err (deg, m):", bufferx_amd.synth.pose_error(cap["pose"], cap["T_gt"]),

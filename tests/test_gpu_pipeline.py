@@ -19,6 +19,9 @@ CASES = {
     "outdoor_small": ("KITTI", "outdoor", 0, 5, False,
                       dict(num_fps=80, num_points_per_patch=64, num_scales=1, search_radius_thresholds=[2],
                            num_points_radius_estimate=200), dict(iter_n=1200)),
+    # BASELINE configs[0] (1 scale, 512 keypoints, 512 points per patch, RANSAC + refinement), minted by the reference's own forward
+    "baseline_cfg0": ("3DMatch", "indoor", 20000, 21, True,
+                      dict(num_fps=512, num_points_per_patch=512, num_scales=1, search_radius_thresholds=[5]), dict(iter_n=4000)),
 }
 
 
@@ -64,7 +67,7 @@ def test_pair_matches_oracle_and_golden(bx, packed, oracle, golden_dir, name):
     assert (n_inl, n_mut, n_ind, scales) == (int(g["num_inliers"]), int(g["num_mutual"]), int(g["num_inlier_ind"]), int(g["scales_used"]))
     assert np.allclose(des_r[:scales], g["des_r"][:scales], atol=1e-6)
     # north_star tolerance: 1e-4 deg / 1e-4 m
-    rre, rte = bx.synth.pose_error(pose, g["pose"])
+    rre, rte = bx.synth.pose_difference(pose, g["pose"])    # well-conditioned at zero (synth.py)
     assert rre < 1e-4 and rte < 1e-4
 
 
