@@ -32,6 +32,10 @@ CASES = {
     "outdoor_small": ("KITTI", "outdoor", 0, 5,
                       dict(num_fps=80, num_points_per_patch=64, num_scales=1, search_radius_thresholds=[2],
                            num_points_radius_estimate=200, iter_n=1200)),
+    # 3 scales with the early exit armed but never taken: two pose-estimation calls (second RANSAC seed stream), cumulative consensus
+    "indoor_3scale": ("3DMatch", "indoor_identical", 8000, 17,
+                      dict(num_fps=256, num_points_per_patch=128, num_scales=3, search_radius_thresholds=[5, 2, 0.5],
+                           num_points_radius_estimate=256, iter_n=4000, enable_early_exit=True, early_exit_min_inliers=10 ** 6)),
     # BASELINE configs[0]: 1 scale, 512 FPS keypoints, 512 points per patch, RANSAC + refinement, the config's own 2000 radius keypoints
     "baseline_cfg0": ("3DMatch", "indoor_identical", 20000, 21,
                       dict(num_fps=512, num_points_per_patch=512, num_scales=1, search_radius_thresholds=[5], iter_n=4000)),

@@ -19,6 +19,10 @@ CASES = {
     "outdoor_small": ("KITTI", "outdoor", 0, 5, False,
                       dict(num_fps=80, num_points_per_patch=64, num_scales=1, search_radius_thresholds=[2],
                            num_points_radius_estimate=200), dict(iter_n=1200)),
+    # 3 scales, early exit armed but never taken (two pose-estimation calls)
+    "indoor_3scale": ("3DMatch", "indoor", 8000, 17, True,
+                      dict(num_fps=256, num_points_per_patch=128, num_scales=3, search_radius_thresholds=[5, 2, 0.5],
+                           num_points_radius_estimate=256), dict(iter_n=4000, enable_early_exit=True, early_exit_min_inliers=10 ** 6)),
     # BASELINE configs[0] (1 scale, 512 keypoints, 512 points per patch, RANSAC + refinement), minted by the reference's own forward
     "baseline_cfg0": ("3DMatch", "indoor", 20000, 21, True,
                       dict(num_fps=512, num_points_per_patch=512, num_scales=1, search_radius_thresholds=[5]), dict(iter_n=4000)),
