@@ -32,6 +32,10 @@ CASES = {
     "outdoor_small": ("KITTI", "outdoor", 0, 5,
                       dict(num_fps=80, num_points_per_patch=64, num_scales=1, search_radius_thresholds=[2],
                            num_points_radius_estimate=200, iter_n=1200)),
+    # outdoor configuration over 3 scales: aligned z, confidence 1.0 (all iter_n RANSAC iterations), no refinement -> binary64 pose
+    "outdoor_3scale": ("KITTI", "outdoor", 0, 9,
+                       dict(num_fps=128, num_points_per_patch=64, num_scales=3, search_radius_thresholds=[5, 2, 0.5],
+                            num_points_radius_estimate=200, iter_n=1200)),
     # 3 scales with the early exit armed but never taken: two pose-estimation calls (second RANSAC seed stream), cumulative consensus
     "indoor_3scale": ("3DMatch", "indoor_identical", 8000, 17,
                       dict(num_fps=256, num_points_per_patch=128, num_scales=3, search_radius_thresholds=[5, 2, 0.5],

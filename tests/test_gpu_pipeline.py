@@ -19,6 +19,10 @@ CASES = {
     "outdoor_small": ("KITTI", "outdoor", 0, 5, False,
                       dict(num_fps=80, num_points_per_patch=64, num_scales=1, search_radius_thresholds=[2],
                            num_points_radius_estimate=200), dict(iter_n=1200)),
+    # outdoor configuration (aligned z, confidence 1.0, binary64 un-refined pose) over 3 scales
+    "outdoor_3scale": ("KITTI", "outdoor", 0, 9, False,
+                       dict(num_fps=128, num_points_per_patch=64, num_scales=3, search_radius_thresholds=[5, 2, 0.5],
+                            num_points_radius_estimate=200), dict(iter_n=1200)),
     # 3 scales, early exit armed but never taken (two pose-estimation calls)
     "indoor_3scale": ("3DMatch", "indoor", 8000, 17, True,
                       dict(num_fps=256, num_points_per_patch=128, num_scales=3, search_radius_thresholds=[5, 2, 0.5],
