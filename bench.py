@@ -51,16 +51,27 @@ WORKLOADS = {
 }
 
 
-def profile_json(name):
-    """Numbers that cannot be read from inside the process (rocprofv3 PMC passes of THIS command, committed under profiles/)."""
-    for rnd in ("r02", "r01"):
+def profile_json(name, files=()):
+    """Numbers that cannot be read from inside the process (rocprofv3 PMC passes of THIS command, committed under profiles/).
+    A profile file carries the sha256 of every HIP source it was measured on ("hip_sources_sha", tools/src_sha.py); when one of the
+    `files` the quoted kernel lives in has changed since, the number no longer belongs to the shipped kernel: "_stale" is set and
+    the caller reports null instead of a stale constant."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from src_sha import sha_map
+        now = sha_map()
+    except Exception:
+        now = {}
+    for rnd in ("r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name))) as f:
                 d = json.load(f)
-                d["_file"] = "profiles/%s_%s.json" % (rnd, name)
-                return d
         except Exception:
             continue
+        d["_file"] = "profiles/%s_%s.json" % (rnd, name)
+        then = d.get("hip_sources_sha") or {}
+        d["_stale"] = (not then) or any(then.get(k) != now.get(k) for k in files)
+        return d
     return None
 
 
@@ -196,13 +207,17 @@ def main():
         def harvest(step):
             c = step % depth
             streams[c].synchronize()
+            th = time.perf_counter()
             a, b, gid = evs[step]
             lat.append(a.elapsed_time(b))
             r = results[c]
+            if r.status != 0:       # device-side failure bits (e.g. the bounded spin of the multi-workgroup FPS timed out)
+                raise RuntimeError("pair %d: bx_result.status = 0x%x" % (gid, r.status))
             pose = np.array(r.pose, np.float64).reshape(4, 4)
             if cfg.test.pose_refine is True:
                 pose = pose.astype(np.float32)
             recs.append(D.pack_record(gid, pose, r.num_inliers, r.num_mutual, r.num_inlier_ind, r.scales_used, lat[-1], r.ransac_iters))
+            host_s[0] += time.perf_counter() - th
 
         for step in range(n_steps):
             c = step % depth
@@ -211,17 +226,20 @@ def main():
                 harvest(step - depth)
             gid = rank + world * step
             dp = dpairs[gid % len(dpairs)]
+            th = time.perf_counter()
             with torch.cuda.stream(st):
                 a = torch.cuda.Event(enable_timing=True)
                 b = torch.cuda.Event(enable_timing=True)
                 a.record(st)
                 ctx.register_pair_async(dp["src"], dp["tgt"], dp["aligned"], dp["perm_src"], dp["perm_tgt"], dp["seed"], results[c])
                 b.record(st)
+            host_s[0] += time.perf_counter() - th
             evs.append((a, b, gid))
         for step in range(max(0, n_steps - depth), n_steps):
             harvest(step)
         return lat, recs
 
+    host_s = [0.0]       # host seconds spent enqueueing (the ~170 launches of a pair) and harvesting (record packing), waits excluded
     run(C)               # every context once (first-use costs: code objects, function attributes), before the W warm-up steps
     torch.cuda.synchronize()
     run(args.warmup)
@@ -229,8 +247,10 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    host_s[0] = 0.0
     t0 = time.perf_counter()
     lat, recs = run(args.steps)
+    host_ms_per_pair = host_s[0] / max(1, args.steps) * 1e3
     allrec = D.gather_records(np.stack(recs), args.steps * world, device=coll_dev)   # the ONE collective (RCCL all-gather)
     torch.cuda.synchronize()
     if world > 1:
@@ -297,8 +317,13 @@ def main():
         # launches that did work: with the early exit taken the kernels of the later scales return at once (device-side skip
         # flag) but are still bracketed by events -- per-launch averages are taken over the scales that ran
         ran = mean_scales / S
-        pmc = profile_json("pmc_traffic")
-        busy = profile_json("mfma_busy")
+        CONV_SRC = ("k_conv.hip", "k_conv32.hip", "bx_common.h")
+        pmc = profile_json("pmc_traffic", CONV_SRC)
+        pmc_ball = profile_json("pmc_traffic", ("k_ball.hip", "bx_common.h"))
+        busy = profile_json("mfma_busy", CONV_SRC)
+        busy_cn = profile_json("mfma_busy", CONV_SRC + ("k_cost.hip",))
+        fresh = lambda d: d is not None and not d["_stale"]
+        stale_note = lambda d: None if d is None else ("%s (%s)" % (d["_file"], "measured on these kernel sources" if not d["_stale"] else "STALE: the kernel sources changed since that profile, value withheld"))
         # --- dominant kernel: Desc conv stack (8 MFMA launches per cloud per scale)
         conv_ms, conv_n = stages.get("desc_conv", (0.0, 0))
         flops_per_stack = 2.0 * DESC_CONV_MMAC_PER_PATCH * 1e6 * K
@@ -309,10 +334,10 @@ def main():
             roof = {"kernel": "conv_kernel<...> x8 (Cylindrical_Net stack, f32 MFMA)", "bound": "mfma",
                     "achieved": round(ach, 3), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F32_MATRIX_TFLOPS, 4),
-                    "traffic": pmc["desc_conv_stack_bytes_per_launch"] if pmc else None,
-                    "traffic_note": "HBM bytes per stack launch, rocprofv3 PMC (%s); algorithmic in+out maps = 3.27e9" % (pmc["_file"] if pmc else "n/a"),
-                    "mfma_busy": busy.get("desc_conv_stack") if busy else None,
-                    "mfma_busy_note": ("SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMD x SQ_BUSY_CU_CYCLES), time-weighted over the 8 layers (%s)" % busy["_file"]) if busy else None,
+                    "traffic": pmc["desc_conv_stack_bytes_per_launch"] if fresh(pmc) else None,
+                    "traffic_note": "HBM bytes per stack launch, rocprofv3 PMC: %s; algorithmic in+out maps = 3.27e9" % stale_note(pmc),
+                    "mfma_busy": busy.get("desc_conv_stack") if fresh(busy) else None,
+                    "mfma_busy_note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), time-weighted over the 8 layers: %s" % stale_note(busy),
                     "avg_launch_ms": round(conv_ms / conv_n, 4), "launches": conv_n,
                     "algorithmic_flops_per_launch": flops_per_stack,
                     "note": "hipEvent-timed on the kernels' stream, one pair in flight, %d pairs right after the timed region" % NPROF}
@@ -325,7 +350,7 @@ def main():
             ach = fl / (pose_ms / pose_n * 1e-3) / 1e12
             roof_cn = {"kernel": "cost_l1_kernel + conv_kernel x9 + soft_argmax (CostNet)", "bound": "mfma", "achieved": round(ach, 3),
                        "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MATRIX_TFLOPS, 4),
-                       "traffic": None, "mfma_busy": busy.get("costnet") if busy else None,
+                       "traffic": None, "mfma_busy": busy_cn.get("costnet") if fresh(busy_cn) else None,
                        "avg_launch_ms": round(pose_ms / pose_n, 4), "launches": pose_n,
                        "algorithmic_flops_per_launch": fl, "mean_matches_per_launch": round(mean_m, 1)}
         # --- the HBM-bound stage the north-star names: neighbour gather.  Algorithmic bytes per (cloud, scale) call:
@@ -344,7 +369,7 @@ def main():
             kach = nbytes / (ng_ms / ng_n * 1e-3) / 1e9
             roof_ng = {"kernel": "neighbour-gather STAGE (batched grid + row-table build, ball_query_kernel)", "bound": "hbm",
                        "achieved": round(ach, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
-                       "traffic": pmc.get("ball_query_bytes_per_launch") if pmc else None,
+                       "traffic": pmc_ball.get("ball_query_bytes_per_launch") if fresh(pmc_ball) else None,
                        "avg_launch_ms": round(stage_ms, 4), "launches": ng_n, "algorithmic_bytes_per_launch": nbytes,
                        "grid_build_ms_per_pair": round(gb_ms / max(gb_n, 1), 4),
                        "query_kernel_avg_ms": round(ng_ms / ng_n, 4), "query_kernel_frac": round(kach / PEAK_HBM_GBS, 4),
@@ -364,6 +389,9 @@ def main():
             "config": {"workload": wl_text % (S, K, P),
                        "pairs_in_flight_per_gpu": C, "parallelism": "pair-sharded x%d, one all-gather of %d B float64 records" % (world, 8 * D.RECORD),
                        "weights": "seeded random (reference snapshot layout)", "mean_points_per_cloud": nmean},
+            "host_ms_per_pair": round(host_ms_per_pair, 3),
+            "host_note": "CPU time of one rank per pair inside the timed region: enqueueing the launches of bx_register_pair + packing the "
+                         "result record (stream waits excluded); a rank is host-bound only when this approaches ms_per_step",
             "registered_ok": "%d/%d" % (ok, len(us)), "registered_pairs_per_s": round(value * ok / max(1, len(us)), 4),
             "work": work,
             "roofline": roof, "roofline_costnet": roof_cn, "roofline_neighbour_gather": roof_ng,

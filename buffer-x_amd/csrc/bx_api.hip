@@ -328,7 +328,11 @@ int pose_stack(bx_ctx* c, hipStream_t s, const float* s_equi, const float* t_equ
                const int32_t* m_dev, int max_m, float* ind, float* logits_out)
 {
     int rc;
-    if ((rc = bxk_cost_l1(c, s, s_equi, t_equi, s_mids, t_mids, m_dev, max_m, c->act0)) != BX_OK) return rc;
+    // layer 0 on the implicit cost volume: the collapsed binary64 form (k_cost.hip) unless BX_COST_L0=direct asks for the fp32 MFMA
+    // convolution of the volume (round-1/2 kernel, kept for A/B measurements; its arithmetic contract is the oracle's "direct" form)
+    if (c->cost_direct) rc = bxk_cost_l1(c, s, s_equi, t_equi, s_mids, t_mids, m_dev, max_m, c->act0);
+    else rc = bxk_cost_l0(c, s, s_equi, t_equi, s_mids, t_mids, m_dev, max_m, c->act0);
+    if (rc != BX_OK) return rc;
     float* bufs[2] = {c->act0, c->act1};
     const float* in = c->act0;
     for (int l = 1; l < BX_NPOSE; ++l) {
@@ -362,6 +366,8 @@ static int create_impl(bx_ctx* c, int device_id)
         // at ~90 % matrix-pipe occupancy and the chip lowers its clock as the occupancy rises), the 16x16x4 form is the default.
         e = getenv("BX_CONV32");
         c->use_conv32 = (e && atoi(e) != 0) ? 1 : 0;
+        e = getenv("BX_COST_L0");
+        c->cost_direct = (e && strcmp(e, "direct") == 0) ? 1 : 0;
     }
     (void)p;
     c->prof = new std::vector<ProfEvt>();
@@ -478,6 +484,7 @@ int bx_destroy(bx_ctx* c)
     for (int i = 0; i < BX_MAX_TILES; ++i) if (c->ev_tile[i]) (void)hipEventDestroy(c->ev_tile[i]);
     (void)hipFree(c->arena);
     (void)hipFree(c->kiss_ws);
+    (void)hipFree(c->d_cost_wp); (void)hipFree(c->d_cost_wq);
     (void)hipFree(c->d_centres); (void)hipFree(c->d_rot); (void)hipFree(c->d_rowc); (void)hipFree(c->d_rad_thr);
     (void)hipFree(c->d_pnt_w); (void)hipFree(c->d_pnt_b); (void)hipFree(c->d_pool_w1); (void)hipFree(c->d_pool_b1); (void)hipFree(c->d_pool_w2); (void)hipFree(c->d_pool_b2);
     for (int i = 0; i < BX_NDESC; ++i) { (void)hipFree(c->desc[i].W); (void)hipFree(c->desc[i].W32); (void)hipFree(c->desc[i].b); (void)hipFree(c->desc[i].lrow); (void)hipFree(c->desc[i].lrow2); (void)hipFree(c->desc[i].obase); (void)hipFree(c->desc[i].toff); }
@@ -621,6 +628,7 @@ int bx_load_weights(bx_ctx* c, const bx_weights* w)
         if ((rc = upload_geo(L, vg)) != BX_OK) return rc;
         for (int i = 0; i < 3; ++i) dims[i] = o[i];
     }
+    if ((rc = bxk_cost_l0_weights(w->pose_w[0], &c->d_cost_wp, &c->d_cost_wq)) != BX_OK) return rc;
     c->weights_loaded = true;
     return BX_OK;
 }

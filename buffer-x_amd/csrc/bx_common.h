@@ -181,6 +181,8 @@ struct bx_ctx {
     int conv_cap[2][BX_NPOSE];          // persistent-grid size of every conv layer on THIS device (0 = not set up yet)
     int conv32_cap[BX_NDESC];           // the same for the 32x32x2 kernels (k_conv32.hip)
     int conv_persist, conv_cap_override, n_cu, use_conv32;
+    double *d_cost_wp, *d_cost_wq;      // collapsed CostNet layer 0 (k_cost.hip): binary64 weights of the P / Q convolutions
+    int cost_direct;                    // BX_COST_L0=direct: layer 0 as the fp32 MFMA convolution of the implicit volume (cost_l1_kernel)
     int32_t* conv_ctr;                  // [2 * BX_NDESC] {next group ticket, departed workgroups} of the 32x32x2 kernels' group walk
     bx_capture cap;                     // bx_set_capture: intermediates of one scale copied to caller buffers
     int cap_on;
@@ -216,6 +218,9 @@ int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, cons
 int bxk_conv32(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t* units_dev, int max_units, float* out);
 int bxk_cost_l1(bx_ctx* c, hipStream_t s, const float* s_equi, const float* t_equi, const int32_t* s_mids,
                 const int32_t* t_mids, const int32_t* m_dev, int max_m, float* out);
+int bxk_cost_l0_weights(const float* w0, double** d_wp, double** d_wq);
+int bxk_cost_l0(bx_ctx* c, hipStream_t s, const float* s_equi, const float* t_equi, const int32_t* s_mids, const int32_t* t_mids,
+                const int32_t* m_dev, int max_m, float* out);
 int bxk_desc_head(bx_ctx* c, hipStream_t s, const float* x, int K, float* desc, float* equi);
 int bxk_mutual(bx_ctx* c, hipStream_t s, const float* sd, int ns, const float* td, int nt, int32_t* s_mids, int32_t* t_mids,
                int32_t* count_out);

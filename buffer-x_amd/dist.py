@@ -6,6 +6,8 @@ The record is float64 (192 bytes per pair: 3 404 pairs of 3DMatch + 3DLoMatch = 
 un-refined RANSAC pose is binary64 (every outdoor configuration), so a float32 record would change its last bits when it crosses
 ranks and a sharded run would not be bit-identical to a single-GPU run.  buffer-x_amd/evaluate.py's state rows are float64 for the
 same reason; both travel through gather_rows()."""
+import os
+
 import numpy as np
 
 # float64: pair_id, pose[16] row-major, num_inliers, num_mutual, num_inlier_ind, scales_used, ransac_iters, model_ms, pose dtype (32 / 64)
@@ -44,7 +46,10 @@ def gather_rows(local, n_rows, device=None):
     local = np.asarray(local)
     assert local.ndim == 2 and local.dtype in (np.float32, np.float64)
     W = local.shape[1]
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    live = dist.is_available() and dist.is_initialized()
+    # BX_DIST_FORCE_COLLECTIVE=1 (test hook): a world of one still goes through the collective, so that the RCCL path
+    # (init_process_group("nccl") + all_gather_into_tensor on a device float64 tensor) can be exercised on a 1-GPU box
+    if not live or (dist.get_world_size() == 1 and not os.environ.get("BX_DIST_FORCE_COLLECTIVE")):
         return local[np.argsort(local[:, 0], kind="stable")]
     world = dist.get_world_size()
     per = (n_rows + world - 1) // world

@@ -140,16 +140,31 @@ class Runner:
         return src, tgt, bool(cfg.patch.is_aligned_to_global_z), voxel_size, sphericity
 
     # ------------------------------------------------------------------------------------------ the loop
-    def run(self, pairs, voxel_size=None, replay_rng=True):
+    def run(self, pairs, voxel_size=None, replay_rng=True, rank=0, world=1, pair_seed=None):
         """pairs: list of dicts {src_path, tgt_path, relt_pose [4,4]} (+ anything else, carried through).
-        -> (rows float64 [n, evaluate.STATE_W] ordered by pair index, poses list) ; rows feed evaluate.gather_states / summarize."""
+        -> (rows float64 [n_mine, evaluate.STATE_W] ordered by pair index, poses list indexed like `pairs`, None for pairs of other
+        ranks); rows feed evaluate.gather_states / summarize.
+
+        Sharding (the reference's loop, test.py:132-146, is one process): rank r of `world` takes the pairs {i : i mod world == r}
+        (dist.shard_indices); row ids are GLOBAL pair indices, so evaluate.gather_states() of every rank's rows is the single-rank
+        result.  The reference draws every random number of the loop from ONE global NumPy stream, which no sharded run can replay;
+        `pair_seed` makes a pair's draws a function of the pair alone (np.random.seed(pair_seed + i) in front of pair i), and then
+        any world size produces the same rows bit for bit.  Without it, rng="device" still shards reproducibly (one host draw per
+        pair, consumed for the pairs of the other ranks too); rng="reference" refuses to shard."""
         t, cfg, C = self.torch, self.cfg, self.C
         S = int(cfg.patch.num_scales)
+        if world > 1 and pair_seed is None and self.rng == "reference":
+            raise ValueError("rng='reference' replays ONE global NumPy stream: a sharded run needs pair_seed (per-pair streams)")
+        n_all = len(pairs)
+        mine = list(range(rank, n_all, world))
+        gids = mine                                   # local position -> global pair index
+        pairs = [pairs[i] for i in mine]
         n = len(pairs)
         depth = min(n, C + 2)
         tickets = [self.pf.submit(p["src_path"], p["tgt_path"]) for p in pairs[:depth]]
-        rows, poses = [None] * n, [None] * n
+        rows, poses = [None] * n, [None] * n_all
         pending = [None] * C
+        next_draw = 0                                 # global index of the next pair whose host draw has not been consumed
 
         def harvest(c):
             if pending[c] is None:
@@ -162,17 +177,25 @@ class Runner:
             pose = np.array(r.pose, np.float64).reshape(4, 4)
             if cfg.test.pose_refine is True:
                 pose = pose.astype(np.float32)
-            poses[i] = pose
+            poses[gids[i]] = pose
             # the reference's collate hands the ground truth over as float32 (dataset/dataloader.py:113), so RTE / RRE of a refined
             # (float32) pose are float32 arithmetic in test.py:168-170: same dtype here, or the 6-decimal CSV cells can differ
             gt = np.asarray(pairs[i]["relt_pose"], np.float32)
-            rows[i] = evaluate.pack_state(i, pose, gt, r.num_inliers, r.num_mutual, r.num_inlier_ind,
+            rows[i] = evaluate.pack_state(gids[i], pose, gt, r.num_inliers, r.num_mutual, r.num_inlier_ind,
                                           r.scales_used, data_s, a.elapsed_time(b) / 1e3, [0.0, 0.0, 0.0],
                                           cfg.test.rte_thresh, cfg.test.rre_thresh)
             pending[c] = None
 
         for i in range(n):
             t0 = time.perf_counter()
+            if pair_seed is not None:
+                np.random.seed((int(pair_seed) + gids[i]) % (2 ** 32))
+            elif world > 1:
+                # rng="device": the pairs of the other ranks consume their ONE host draw too (same global stream as a single rank)
+                while next_draw < gids[i]:
+                    np.random.randint(0, 2**31 - 1)
+                    next_draw += 1
+                next_draw = gids[i] + 1
             with t.cuda.stream(self.prep_stream):
                 bufs = self.sets[i % (C + 1)]
                 src, tgt, aligned, _, _ = self._prepare(tickets[i], voxel_size, replay_rng, bufs)
@@ -235,14 +258,23 @@ def threedmatch_test_pairs(root, benchmark="3DMatch", scenes=THREEDMATCH_TEST_SC
     return pairs
 
 
-def run_3dmatch(cfg, packed_weights, root, benchmark="3DMatch", timestr="run", out_root=".", scenes=THREEDMATCH_TEST_SCENES, **runner_kw):
-    """test.py for the 3DMatch / 3DLoMatch test split on one GPU: pair list -> Runner -> .log files -> RMSE recall + summary."""
+def run_3dmatch(cfg, packed_weights, root, benchmark="3DMatch", timestr="run", out_root=".", scenes=THREEDMATCH_TEST_SCENES,
+                rank=0, world=1, pair_seed=None, collective_device=None, **runner_kw):
+    """test.py for the 3DMatch / 3DLoMatch test split: pair list -> Runner -> .log files -> RMSE recall + summary.
+    world > 1 (one process per GPU, torch.distributed initialised by the caller): every rank registers its pairs {i mod world ==
+    rank}, ONE all-gather of the float64 state rows (evaluate.gather_states; RCCL when collective_device is a cuda device) makes
+    every rank hold all rows, rank 0 writes the .log files and evaluates them; the other ranks return (rows, None)."""
     pairs = threedmatch_test_pairs(root, benchmark, scenes)
     run = Runner(cfg, packed_weights, **runner_kw)
     try:
-        rows, poses = run.run(pairs)
+        rows, poses = run.run(pairs, rank=rank, world=world, pair_seed=pair_seed)
     finally:
         run.close()
+    if world > 1:
+        rows = evaluate.gather_states(rows, len(pairs), device=collective_device)
+        poses = [evaluate.state_pose(r) for r in rows]
+        if rank != 0:
+            return rows, None
     evaluate.write_3dmatch_logs(benchmark, timestr, [(p["src_id"], p["tgt_id"], pose) for p, pose in zip(pairs, poses)], root=out_root)
     gtpath = os.path.join(root, "test", benchmark, "gt_result") if benchmark == "3DMatch" else os.path.join(root, "test", benchmark)
     scenes, rmse_recall = evaluate.evaluate_3dmatch(gtpath, benchmark, timestr, root=out_root)

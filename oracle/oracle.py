@@ -175,6 +175,16 @@ def cost_volume(s_equi, t_equi, s_mids, t_mids, ele_n=7, azi_n=20):
     return out
 
 
+def cost_l0(s_equi, t_equi, s_mids, t_mids, W0, b0, ele_n=7, azi_n=20):
+    """CostNet layer 0 on the implicit cost volume (bxo_cost_l0): [m][2][(A-2)(H-2)(A-2)][16], ReLU applied."""
+    s_equi, t_equi, s_mids, t_mids, W0, b0 = _f(s_equi), _f(t_equi), _i(s_mids), _i(t_mids), _f(W0), _f(b0)
+    m = len(s_mids)
+    out = np.zeros((m, 2, (azi_n - 2) * (ele_n - 4) * (azi_n - 2), 16), np.float32)
+    lib().bxo_cost_l0(_p(s_equi), _p(t_equi), _p(s_mids), _p(t_mids), C.c_int(m), C.c_int(ele_n), C.c_int(azi_n), _p(W0), _p(b0),
+                      _p(out))
+    return out
+
+
 def soft_argmax(logits, azi_n=20):
     logits = _f(logits)
     m = logits.shape[0]

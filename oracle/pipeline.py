@@ -6,8 +6,13 @@ stage by stage, on the C oracle.  Randomness is explicit (seed): permutation str
 RANSAC call c uses mix64(seed, 0x5AC0000 + c), the >200k-point subsample of the radius estimation
 uses stream 0x200 (the reference uses unseeded torch.randint, models/BUFFERX.py:664-665).
 """
+import os
 import numpy as np
 from . import oracle as O
+
+# which restatement of CostNet layer 0 the chain uses: "direct" = fp32 convolution of the materialised cost volume (the contract of
+# cost_l1_kernel), "collapsed" = bxo_cost_l0 (binary64 P - Q form)
+COST_L0 = os.environ.get("BX_ORACLE_COST_L0", "collapsed")
 
 
 def _w():
@@ -40,8 +45,14 @@ def desc_forward(cloud, kpts, des_r, aligned, perm, pw, cfg, cap=None, tag=""):
 
 def pose_forward(s_equi, t_equi, s_mids, t_mids, pw, cfg, cap=None, tag=""):
     W = _w()
-    x = O.cost_volume(s_equi, t_equi, s_mids, t_mids, cfg.patch.ele_n, cfg.patch.azi_n)
-    for L, (dims, k, out) in zip(pw["pose"], W.pose_geometry(cfg.patch.ele_n, cfg.patch.azi_n)):
+    layers = list(zip(pw["pose"], W.pose_geometry(cfg.patch.ele_n, cfg.patch.azi_n)))
+    if COST_L0 == "collapsed":
+        # layer 0 on the implicit cost volume: the collapsed binary64 form (bxo_cost_l0); layers 1..9 are explicit convolutions
+        x = O.cost_l0(s_equi, t_equi, s_mids, t_mids, pw["pose"][0]["W"], pw["pose"][0]["b"], cfg.patch.ele_n, cfg.patch.azi_n)
+        layers = layers[1:]
+    else:
+        x = O.cost_volume(s_equi, t_equi, s_mids, t_mids, cfg.patch.ele_n, cfg.patch.azi_n)
+    for L, (dims, k, out) in layers:
         tap, _ = W.valid_tap_table(dims, k)
         x = O.conv(x, tap, L["W"], L["b"], L["relu"])
     ind = O.soft_argmax(x, cfg.patch.azi_n)

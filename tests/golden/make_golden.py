@@ -43,11 +43,23 @@ CASES = {
     # BASELINE configs[0]: 1 scale, 512 FPS keypoints, 512 points per patch, RANSAC + refinement, the config's own 2000 radius keypoints
     "baseline_cfg0": ("3DMatch", "indoor_identical", 20000, 21,
                       dict(num_fps=512, num_points_per_patch=512, num_scales=1, search_radius_thresholds=[5], iter_n=4000)),
+    # BASELINE configs[1] at its REAL size: 3 scales, 5000 FPS keypoints, 1024 points per patch, RANSAC + refinement, every other knob
+    # the reference's own 3DMatch default; the pair is one of bench.py's registering "shared" fragments (~30k points per cloud)
+    "headline_cfg1": ("3DMatch", "indoor_shared", 30000, 100, dict(num_fps=5000, num_points_per_patch=1024, sub_stride=256, row_stride=4)),
+    # BASELINE configs[4] geometry at its real size: the reference's TIERS_hetero configuration (outdoor parameters: aligned z,
+    # confidence 1.0, no refinement) with the early exit enabled -- and taken after scale 0 (>= 50 RANSAC inliers)
+    "tiers_early": ("TIERS_hetero", "tiers", 0, 100, dict(num_fps=5000, num_points_per_patch=1024, enable_early_exit=True,
+                                                           sub_stride=256, row_stride=4)),
+    # BASELINE configs[2] geometry at its real size: two ~120k-point LiDAR sweeps, the reference's KITTI configuration (aligned z,
+    # confidence 1.0 = all 50 000 RANSAC iterations, no refinement -> binary64 pose), 3 scales, 5000 keypoints, 1024 points per patch
+    "kitti_cfg2": ("KITTI", "kitti_full", 0, 100, dict(num_fps=5000, num_points_per_patch=1024, sub_stride=256, row_stride=4)),
 }
 
 
 def apply_overrides(cfg, ov):
     for k, v in ov.items():
+        if k in ("sub_stride", "row_stride"):    # fixture thinning, not configuration
+            continue
         if k in ("iter_n", "enable_early_exit", "early_exit_min_inliers"):
             cfg.match[k] = v
         else:
@@ -59,6 +71,12 @@ def case_inputs(name):
     ds, kind, n, seed, ov = CASES[name]
     if kind == "indoor":
         pair = bufferx_amd.synth.make_pair(seed, "indoor", n_target=n)
+    elif kind == "indoor_shared":
+        pair = bufferx_amd.synth.make_pair(seed, "indoor", n_target=n, shared=True)
+    elif kind == "tiers":
+        pair = bufferx_amd.synth.make_tiers_pair(seed)
+    elif kind == "kitti_full":
+        pair = bufferx_amd.synth.make_pair(seed, "outdoor", voxel=0.02)
     elif kind == "indoor_identical":
         pair = bufferx_amd.synth.make_pair(seed, "indoor", n_target=n, identical=True)
     else:
@@ -145,11 +163,13 @@ def run_reference(name):
     for j, d in enumerate(desc_calls):
         i, c = divmod(j, 2)
         tag = f"s{i}_{'src' if c == 0 else 'tgt'}_"
-        cap[tag + "desc"] = d["desc"]
-        cap[tag + "R"] = d["R"]
-        # keep fixtures small: a strided sample of the equivariant maps and the normalised patches
-        cap[tag + "equi_sub"] = d["equi"][::16]
-        cap[tag + "patches_sub"] = d["patches"][::16]
+        # keep fixtures small: every row_stride-th descriptor / rotation, a strided sample of the equivariant maps and the patches
+        rs = ov.get("row_stride", 1)
+        cap[tag + "desc"] = d["desc"][::rs]
+        cap[tag + "R"] = d["R"][::rs]
+        st = ov.get("sub_stride", 16)
+        cap[tag + "equi_sub"] = d["equi"][::st]
+        cap[tag + "patches_sub"] = d["patches"][::st * (2 if rs > 1 else 1)]
     for i, (s, t) in enumerate(mm):
         cap[f"s{i}_s_mids"], cap[f"s{i}_t_mids"] = s.astype(np.int32), t.astype(np.int32)
     for i, v in enumerate(inds):
@@ -158,6 +178,8 @@ def run_reference(name):
         cap[f"est{i}_inlier_ind"] = ind.astype(np.int32)
         cap[f"est{i}_T"] = T
         cap[f"est{i}_n"] = n
+    cap["sub_stride"] = ov.get("sub_stride", 16)
+    cap["row_stride"] = ov.get("row_stride", 1)
     cap["ransac_log"] = np.array(rh.RANSAC_STATE["log"], np.int64)
     cap["T_gt"] = pair["T_gt"]
     cap["n_src"], cap["n_tgt"] = len(src), len(tgt)

@@ -268,28 +268,45 @@ def test_mutual(ctx, oracle):
 
 
 # ------------------------------------------------------------------ CostNet + soft-argmax (row 12)
-def test_pose_net(ctx, oracle, bx, packed):
+@pytest.mark.parametrize("form", ["collapsed", "direct"])
+def test_pose_net(oracle, bx, packed, form, monkeypatch):
+    """CostVolume + CostNet + soft-argmax (models/BUFFERX.py:39-69, models/patchnet.py:192-210), logits and ind bit-exact.
+    collapsed: layer 0 = bxo_cost_l0 (binary64 P - Q form, k_cost.hip, the default); direct: layer 0 = the fp32 convolution of the
+    materialised cost volume (cost_l1_kernel, BX_COST_L0=direct)."""
     import torch
+    from bufferx_amd import lib
     rng = np.random.default_rng(5)
     K = 40
     se = rng.standard_normal((K, 140, 32)).astype(np.float32)
     te = rng.standard_normal((K, 140, 32)).astype(np.float32)
     se /= np.linalg.norm(se, axis=2, keepdims=True)
     te /= np.linalg.norm(te, axis=2, keepdims=True)
+    te[:8] = se[:8] + 0.01 * rng.standard_normal((8, 140, 32)).astype(np.float32)     # nearly equal maps: P - Q cancels
     m = 23
     sm = rng.permutation(K)[:m].astype(np.int32)
     tm = rng.permutation(K)[:m].astype(np.int32)
-    x = oracle.cost_volume(se, te, sm, tm)
-    for L, (dims, k, _) in zip(packed["pose"], bx.weights.pose_geometry()):
+    sm[:8] = np.arange(8); tm[:8] = np.arange(8)
+    layers = list(zip(packed["pose"], bx.weights.pose_geometry()))
+    if form == "collapsed":
+        x = oracle.cost_l0(se, te, sm, tm, packed["pose"][0]["W"], packed["pose"][0]["b"])
+        layers = layers[1:]
+    else:
+        x = oracle.cost_volume(se, te, sm, tm)
+    for L, (dims, k, _) in layers:
         tap, _ = bx.weights.valid_tap_table(dims, k)
         x = oracle.conv(x, tap, L["W"], L["b"], L["relu"])
     rind = oracle.soft_argmax(x)
     smp = np.zeros(K, np.int32); smp[:m] = sm
     tmp = np.zeros(K, np.int32); tmp[:m] = tm
-    from bufferx_amd import lib
-    ind, logits = ctx.pose_net(se, te, smp, tmp, torch.tensor([m], dtype=torch.int32), K, want_logits=True)
-    assert np.array_equal(lib.chunked_to_logical(_np(logits))[:m], x)
-    assert np.array_equal(_np(ind)[:m], rind)
+    if form == "direct":
+        monkeypatch.setenv("BX_COST_L0", "direct")
+    c = lib.Context(_cfg(bx, K=64, P=64, S=1, nk=64), max_points=4096, device=0, packed_weights=packed)
+    try:
+        ind, logits = c.pose_net(se, te, smp, tmp, torch.tensor([m], dtype=torch.int32), K, want_logits=True)
+        assert np.array_equal(lib.chunked_to_logical(_np(logits))[:m], x)
+        assert np.array_equal(_np(ind)[:m], rind)
+    finally:
+        c.close()
 
 
 # ------------------------------------------------------------------ hypotheses + consensus (row 13)

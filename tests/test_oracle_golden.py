@@ -93,3 +93,32 @@ def test_oracle_pipeline_matches_reference(bx, packed, golden_dir, name):
     assert (n_inl, n_mut, n_ind) == (int(g["num_inliers"]), int(g["num_mutual"]), int(g["num_inlier_ind"]))
     rre, rte = bx.synth.pose_difference(np.asarray(pose, np.float64), g["pose"])   # well-conditioned at zero (synth.py)
     assert rre < 1e-4 and rte < 1e-4      # north_star tolerance: 1e-4 deg / 1e-4 m
+
+
+# ------------------------------------------------------------------ the real-size fixtures (K = 5000 / P = 1024 / S = 3)
+@pytest.mark.skipif(not os.environ.get("BX_RUN_BIG_ORACLE"), reason="3-4 CPU-minutes per case: set BX_RUN_BIG_ORACLE=1 (results quoted in DESIGN.md section 4)")
+@pytest.mark.parametrize("name", ["headline_cfg1", "kitti_cfg2", "tiers_early"])
+def test_oracle_matches_reference_at_real_size(bx, packed, golden_dir, name):
+    """The CPU oracle pipeline against the fixture minted by the reference's own forward at BASELINE configs[1] / [2] / [4] size:
+    identical counts, mutual sets, consensus set; pose within 1e-4 deg / 1e-4 m; >= 99.8 % of the sampled descriptor rows within 2e-5."""
+    from oracle import pipeline as PL
+    from test_gpu_headline import big_case
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg, pair, seed = big_case(bx, name)
+    cap = {}
+    pose, n_inl, n_mut, n_ind, scales = PL.register_pair(pair["src"], pair["tgt"], packed, cfg, pair["aligned_z"], seed, cap)
+    assert scales == int(g["scales_used"])
+    assert (n_inl, n_mut, n_ind) == (int(g["num_inliers"]), int(g["num_mutual"]), int(g["num_inlier_ind"]))
+    rs = int(g["row_stride"])
+    for i in range(scales):
+        assert cap[f"s{i}_des_r"] == pytest.approx(float(g["des_r"][i]), abs=1e-12)
+        for c in ("src", "tgt"):
+            d = np.abs(cap[f"s{i}_{c}_desc"][::rs].astype(np.float64) - g[f"s{i}_{c}_desc"]).max(1)
+            assert (d < 2e-5).mean() >= 0.998
+        assert np.array_equal(cap[f"s{i}_s_mids"], g[f"s{i}_s_mids"]) and np.array_equal(cap[f"s{i}_t_mids"], g[f"s{i}_t_mids"])
+    k = 0
+    while f"est{k}_T" in g:
+        k += 1
+    assert np.array_equal(cap[f"s{scales - 1}_inlier_ind"], g[f"est{k - 1}_inlier_ind"])
+    rre, rte = bx.synth.pose_difference(np.asarray(pose, np.float64), g["pose"])
+    assert rre < 1e-4 and rte < 1e-4
