@@ -35,7 +35,10 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32
 PEAK_HBM_GBS = 8000.0            # HBM3E spec (6.29 TB/s measured achievable)
 DESC_CONV_MMAC_PER_PATCH = 3.871 + 5.161 + 10.322 + 20.644 + 10.322 + 5.161 + 2.580 + 1.290
-COSTNET_MMAC_PER_MATCH = 80.0
+COSTNET_MMAC_PER_MATCH = 80.0    # the reference's CostNet on the materialised 20-shift cost volume
+# what the shipped kernels execute: layer 0 collapsed to its P - Q form (k_cost.hip: 1.42 MMAC of binary64 VALU work instead of the
+# 26.87 MMAC fp32 convolution of the volume); the remaining 53.1 MMAC of layers 1..9 are f32 MFMA work
+COSTNET_L0_MMAC, COSTNET_L0_COLLAPSED_MMAC = 26.873, 1.42
 
 WORKLOADS = {
     "3dmatch": ("3DMatch", "3DMatch-like synthetic pairs (noise-free partial-overlap fragments of one voxelised scene sample), "
@@ -346,10 +349,17 @@ def main():
         roof_cn = None
         if pose_n:
             pose_n = max(1, int(round(pose_n * ran)))
-            fl = 2.0 * COSTNET_MMAC_PER_MATCH * 1e6 * mean_m
+            direct = os.environ.get("BX_COST_L0") == "direct"
+            mmac = COSTNET_MMAC_PER_MATCH if direct else COSTNET_MMAC_PER_MATCH - COSTNET_L0_MMAC      # MFMA work that is executed
+            fl = 2.0 * mmac * 1e6 * mean_m
             ach = fl / (pose_ms / pose_n * 1e-3) / 1e12
-            roof_cn = {"kernel": "cost_l1_kernel + conv_kernel x9 + soft_argmax (CostNet)", "bound": "mfma", "achieved": round(ach, 3),
+            roof_cn = {"kernel": ("cost_l1_kernel" if direct else "cost_l0_kernel (collapsed layer 0, binary64 VALU)") + " + conv_kernel x9 + soft_argmax (CostNet)",
+                       "bound": "mfma", "achieved": round(ach, 3),
                        "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MATRIX_TFLOPS, 4),
+                       "flops_note": "executed f32 MFMA flops (layers 1..9: %.1f MMAC per match%s) over the time of the WHOLE CostNet incl. layer 0; "
+                                     "reference-equivalent work = 80.0 MMAC per match -> %.1f TFLOP/s equivalent"
+                                     % (mmac, "" if direct else "; layer 0 costs 1.42 MMAC of binary64 fma instead of 26.9 MMAC",
+                                        2.0 * COSTNET_MMAC_PER_MATCH * 1e6 * mean_m / (pose_ms / pose_n * 1e-3) / 1e12),
                        "traffic": None, "mfma_busy": busy_cn.get("costnet") if fresh(busy_cn) else None,
                        "avg_launch_ms": round(pose_ms / pose_n, 4), "launches": pose_n,
                        "algorithmic_flops_per_launch": fl, "mean_matches_per_launch": round(mean_m, 1)}
@@ -388,7 +398,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl_text % (S, K, P),
                        "pairs_in_flight_per_gpu": C, "parallelism": "pair-sharded x%d, one all-gather of %d B float64 records" % (world, 8 * D.RECORD),
-                       "weights": "seeded random (reference snapshot layout)", "mean_points_per_cloud": nmean},
+                       "weights": "seeded random (reference snapshot layout)", "mean_points_per_cloud": nmean,
+                       "workload_generator": "synth.make_pair v2 (round 2+: shared=True noise-free partial-overlap fragments; round 1 used "
+                                             "independently sampled jittered fragments = --workload 3dmatch-noisy; rates of the two are not comparable)"},
             "host_ms_per_pair": round(host_ms_per_pair, 3),
             "host_note": "CPU time of one rank per pair inside the timed region: enqueueing the launches of bx_register_pair + packing the "
                          "result record (stream waits excluded); a rank is host-bound only when this approaches ms_per_step",

@@ -2,6 +2,7 @@
 // the whole-pair pipeline (reference BufferX.forward inference branch, models/BUFFERX.py:257-467).
 #include "bx_common.h"
 #include <atomic>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -40,10 +41,32 @@ struct ProfScope {
 
 }  // namespace
 
-// contexts alive per device (this process): the FPS launcher sizes its XCD co-location by it (k_fps.hip)
+// contexts alive per device (this process) and per XCD pair: the FPS launcher aims the co-located launches of a context at one of the
+// four XCD pairs and sizes the co-location by the contexts that REALLY share that pair (k_fps.hip).  A slot is released in bx_destroy:
+// contexts that come and go (model.py re-creates its context for a larger cloud, bench.py opens and closes one) do not pile up on one pair.
 static std::atomic<int> g_live[64];
-static std::atomic<int> g_created[64];
+static std::mutex g_slot_mu;
+static int g_slot_use[64][4];
 int bx_live_contexts(int device) { return device >= 0 && device < 64 ? g_live[device].load() : 1 << 20; }
+int bx_xcd_pair_sharing(int device, int pair)
+{
+    if (device < 0 || device >= 64 || pair < 0 || pair > 3) return 1 << 20;
+    std::lock_guard<std::mutex> lk(g_slot_mu);
+    return g_slot_use[device][pair];
+}
+static int xcd_slot_take(int device)
+{
+    std::lock_guard<std::mutex> lk(g_slot_mu);
+    int best = 0;
+    for (int p = 1; p < 4; ++p) if (g_slot_use[device][p] < g_slot_use[device][best]) best = p;
+    ++g_slot_use[device][best];
+    return best;
+}
+static void xcd_slot_release(int device, int pair)
+{
+    std::lock_guard<std::mutex> lk(g_slot_mu);
+    if (g_slot_use[device][pair] > 0) --g_slot_use[device][pair];
+}
 
 // event bracket usable from the other translation units (tag 12 = the neighbour-gather query kernel alone)
 void bx_prof_mark(bx_ctx* c, hipStream_t s, int tag, int begin)
@@ -446,7 +469,7 @@ int bx_create(int device_id, const bx_params* params, bx_ctx** out)
     memset(c, 0, sizeof(*c));
     c->device = device_id;
     c->p = p;
-    if (device_id < 64) { c->fps_xcd_pair = g_created[device_id].fetch_add(1) & 3; g_live[device_id].fetch_add(1); }
+    if (device_id < 64) { c->fps_xcd_pair = xcd_slot_take(device_id); g_live[device_id].fetch_add(1); }
     const int rc = create_impl(c, device_id);
     if (rc != BX_OK) {
         // bx_destroy releases whatever had been allocated; it must not clobber the message of the failure
@@ -465,7 +488,7 @@ int bx_destroy(bx_ctx* c)
     if (!c) return BX_OK;
     BxDevScope ds(c->device);
     (void)hipDeviceSynchronize();
-    if (c->device >= 0 && c->device < 64) g_live[c->device].fetch_sub(1);
+    if (c->device >= 0 && c->device < 64) { g_live[c->device].fetch_sub(1); xcd_slot_release(c->device, c->fps_xcd_pair); }
     bxk_pre_release(c);
     if (c->prof) {
         auto* v = static_cast<std::vector<ProfEvt>*>(c->prof);
@@ -528,6 +551,7 @@ int bx_set_capture(bx_ctx* c, const bx_capture* cap)
         bx_set_error("bx_set_capture: scale %d / cloud %d out of range", cap->scale, cap->cloud);
         return BX_ERR_ARG;
     }
+    if (c->p.keypoint_tiles > 1) { bx_set_error("bx_set_capture: the latency form (keypoint_tiles > 1) cannot be captured"); return BX_ERR_STATE; }
     c->cap = *cap;
     c->cap_on = 1;
     return BX_OK;

@@ -196,6 +196,7 @@ constexpr int BX_RANSAC_BATCH = 4096;
 int bxk_fps(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* n, int nclouds, int m, int32_t* const* idx_out,
             float* const* kpts_out);
 int bx_live_contexts(int device);   // contexts alive on the device in this process (bx_api.hip)
+int bx_xcd_pair_sharing(int device, int pair);   // live contexts of the device whose co-located FPS launches aim at this XCD pair
 int bxk_fps_range(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* n, int nclouds, int j0, int j1, int m,
                   int32_t* const* idx_out, float* const* kpts_out);
 int bxk_gather_rows(hipStream_t s, const float* pts, const int32_t* idx, int n, float* out);

@@ -345,6 +345,9 @@ int launch32(bx_ctx* c, int layer, hipStream_t s, const ConvLayerDev& L, const f
 int bxk_conv32(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t* units_dev, int max_units, float* out)
 {
     if (units_dev || max_units < 4 || layer >= 6) return -1;
+    // the group walk draws its tickets from ONE counter pair per (context, layer): the latency form runs the source and the target
+    // chain of a pair concurrently on two streams, whose launches of a layer would share it -- the stateless 16x16x4 kernels serve it
+    if (c->p.keypoint_tiles > 1) return -1;
     const ConvLayerDev& L = c->desc[layer];
     switch (layer) {
         //                      NCHUNK COUT G  RELU

@@ -10,10 +10,11 @@
 // -- 1.42 MMAC per match (a 15-tap circular convolution of S on a 3 x 20 map and a 9-tap convolution of T on a 3 x 18 map).
 // P and Q are individually larger than their difference, so the contract (oracle/bx_oracle.c: bxo_cost_l0) is binary64:
 // weights summed in binary64, accumulators from 0 through an fma chain in the order c > b > delta | d, ((b + P) - Q) rounded to
-// fp32 once, ReLU.  Plain v_fma_f64 on the vector ALUs (full rate on gfx950): one workgroup per match, a wave owns 8 output
+// fp32 once, ReLU.  Plain v_fma_f64 on the vector ALUs (full rate on gfx950): one workgroup per match, a wave owns OT output
 // channels of P or of Q, a lane one map position; the weights of a step are wave-uniform and arrive through the scalar cache.
 // The expanded layer-0 output [m][2][972][16] (what layer 1 consumes) is written with 16-byte coalesced stores.
 #include "bx_common.h"
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -22,28 +23,32 @@ constexpr int AO = A - 2, HO = H - 2;                      // 18 x 3
 constexpr int POUT = AO * HO * AO;                         // 972 output positions
 constexpr int SW = A + 4;                                  // S rows carry a +-2 column wrap-around halo
 constexpr int SCS = H * SW + 1, TCS = H * A + 1;           // channel strides (odd: conflict-free transposing writes)
-constexpr int CT = 512;
 
-template <int ND, int ROWW, int CS>
-__device__ __forceinline__ void pq_chain(const float* __restrict__ sm, int base, const double* __restrict__ w, double (&acc)[8])
+// OT output channels per wave: the weights of a step are OT doubles in SGPRs (one s_load), the step costs 1 LDS read + 1 convert
+// + OT fma.  The chain waits on the weight stream through the scalar cache (197 KB of weights per match against a 16 KB cache).
+// Measured (m = 1458 matches): OT = 8 with 8 waves per workgroup 181 us, OT = 4 with 16 waves (8 waves per SIMD) 200 us -- the
+// extra waves do not pay for the lower fma share of a step; OT = 8 is the default (BX_COST_OT=4 selects the other form).
+template <int OT, int ND, int ROWW, int CS>
+__device__ __forceinline__ void pq_chain(const float* __restrict__ sm, int base, const double* __restrict__ w, double (&acc)[OT])
 {
 #pragma unroll 1
     for (int c = 0; c < 32; ++c) {
         const float* r = sm + c * CS + base;
-        const double* wc = w + (size_t)c * 3 * ND * 8;
+        const double* wc = w + (size_t)c * 3 * ND * OT;
 #pragma unroll
         for (int b = 0; b < 3; ++b)
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 const double x = (double)r[b * ROWW + d];
-                const double* ws = wc + (b * ND + d) * 8;
+                const double* ws = wc + (b * ND + d) * OT;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = fma(ws[j], x, acc[j]);
+                for (int j = 0; j < OT; ++j) acc[j] = fma(ws[j], x, acc[j]);
             }
     }
 }
 
-__global__ __launch_bounds__(CT, 2) void cost_l0_kernel(const float* __restrict__ s_equi, const float* __restrict__ t_equi,
+template <int OT>
+__global__ __launch_bounds__(64 * (64 / OT), 2) void cost_l0_kernel(const float* __restrict__ s_equi, const float* __restrict__ t_equi,
                                                         const int32_t* __restrict__ s_mids, const int32_t* __restrict__ t_mids,
                                                         const int32_t* __restrict__ m_dev, int max_m, const double* __restrict__ Wp,
                                                         const double* __restrict__ Wq, const float* __restrict__ bias,
@@ -58,6 +63,7 @@ __global__ __launch_bounds__(CT, 2) void cost_l0_kernel(const float* __restrict_
     m = m < max_m ? m : max_m;
     const int u = blockIdx.x;
     if (u >= m) return;
+    constexpr int NTILE = 32 / OT, CT = 64 * 2 * NTILE;     // waves [0, NTILE): P tiles, [NTILE, 2 NTILE): Q tiles
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -76,27 +82,27 @@ __global__ __launch_bounds__(CT, 2) void cost_l0_kernel(const float* __restrict_
     }
     __syncthreads();
 
-    // ---- P (waves 0..3) and Q (waves 4..7): 8 output channels per wave, one map position per lane
+    // ---- P (first half of the waves) and Q (second half): OT output channels per wave, one map position per lane
     {
-        const int ot = wave & 3;
-        double acc[8];
+        const int ot = wave % NTILE;
+        double acc[OT];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.0;
-        if (wave < 4) {
+        for (int j = 0; j < OT; ++j) acc[j] = 0.0;
+        if (wave < NTILE) {
             const int pos = lane < HO * A ? lane : 0;
             const int k = pos / A, e = pos - k * A;
-            pq_chain<5, SW, SCS>(sS, k * SW + e, Wp + (size_t)ot * 32 * 15 * 8, acc);
+            pq_chain<OT, 5, SW, SCS>(sS, k * SW + e, Wp + (size_t)ot * 32 * 15 * OT, acc);
             if (lane < HO * A) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) sP[(ot * 8 + j) * 64 + lane] = (double)bias[ot * 8 + j] + acc[j];
+                for (int j = 0; j < OT; ++j) sP[(ot * OT + j) * 64 + lane] = (double)bias[ot * OT + j] + acc[j];
             }
         } else {
             const int pos = lane < HO * AO ? lane : 0;
             const int k = pos / AO, l = pos - k * AO;
-            pq_chain<3, A, TCS>(sT, k * A + l, Wq + (size_t)ot * 32 * 9 * 8, acc);
+            pq_chain<OT, 3, A, TCS>(sT, k * A + l, Wq + (size_t)ot * 32 * 9 * OT, acc);
             if (lane < HO * AO) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) sQ[(ot * 8 + j) * 64 + lane] = acc[j];
+                for (int j = 0; j < OT; ++j) sQ[(ot * OT + j) * 64 + lane] = acc[j];
             }
         }
     }
@@ -125,9 +131,17 @@ __global__ __launch_bounds__(CT, 2) void cost_l0_kernel(const float* __restrict_
 }  // namespace
 
 // Wp / Wq of the collapsed form from the packed layer-0 weights [2][27][16][32] (tap = (a*3 + b)*3 + d): binary64 sums in the
-// order of the oracle (a ascending), device layout [o / 8][c][b][delta | d][o % 8].
+// order of the oracle (a ascending), device layout [o / OT][c][b][delta | d][o % OT].
+static int cost_ot()
+{
+    static int v = 0;
+    if (!v) { const char* e = getenv("BX_COST_OT"); v = (e && atoi(e) == 4) ? 4 : 8; }
+    return v;
+}
+
 int bxk_cost_l0_weights(const float* w0, double** d_wp, double** d_wq)
 {
+    const int OT = cost_ot();
     std::vector<double> Wp((size_t)32 * 3 * 5 * 32, 0.0), Wq((size_t)32 * 3 * 3 * 32, 0.0);
     for (int c = 0; c < 32; ++c)
         for (int b = 0; b < 3; ++b)
@@ -142,8 +156,8 @@ int bxk_cost_l0_weights(const float* w0, double** d_wp, double** d_wq)
     for (int o = 0; o < 32; ++o)
         for (int c = 0; c < 32; ++c)
             for (int b = 0; b < 3; ++b) {
-                for (int d = 0; d < 5; ++d) dp[((((size_t)(o / 8) * 32 + c) * 3 + b) * 5 + d) * 8 + (o % 8)] = Wp[(((size_t)c * 3 + b) * 5 + d) * 32 + o];
-                for (int d = 0; d < 3; ++d) dq[((((size_t)(o / 8) * 32 + c) * 3 + b) * 3 + d) * 8 + (o % 8)] = Wq[(((size_t)c * 3 + b) * 3 + d) * 32 + o];
+                for (int d = 0; d < 5; ++d) dp[((((size_t)(o / OT) * 32 + c) * 3 + b) * 5 + d) * OT + (o % OT)] = Wp[(((size_t)c * 3 + b) * 5 + d) * 32 + o];
+                for (int d = 0; d < 3; ++d) dq[((((size_t)(o / OT) * 32 + c) * 3 + b) * 3 + d) * OT + (o % OT)] = Wq[(((size_t)c * 3 + b) * 3 + d) * 32 + o];
             }
     BX_HIP(hipMalloc(reinterpret_cast<void**>(d_wp), dp.size() * sizeof(double)));
     BX_HIP(hipMemcpy(*d_wp, dp.data(), dp.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -156,8 +170,12 @@ int bxk_cost_l0(bx_ctx* c, hipStream_t s, const float* s_equi, const float* t_eq
                 const int32_t* m_dev, int max_m, float* out)
 {
     if (max_m <= 0) return BX_OK;
-    hipLaunchKernelGGL(cost_l0_kernel, dim3(max_m), dim3(CT), 0, s, s_equi, t_equi, s_mids, t_mids, m_dev, max_m, c->d_cost_wp, c->d_cost_wq,
-                       c->pose[0].b, out, c->skip);
+    if (cost_ot() == 8)
+        hipLaunchKernelGGL(cost_l0_kernel<8>, dim3(max_m), dim3(512), 0, s, s_equi, t_equi, s_mids, t_mids, m_dev, max_m, c->d_cost_wp, c->d_cost_wq,
+                           c->pose[0].b, out, c->skip);
+    else
+        hipLaunchKernelGGL(cost_l0_kernel<4>, dim3(max_m), dim3(1024), 0, s, s_equi, t_equi, s_mids, t_mids, m_dev, max_m, c->d_cost_wp, c->d_cost_wq,
+                           c->pose[0].b, out, c->skip);
     BX_LAUNCH_CHECK();
     return BX_OK;
 }

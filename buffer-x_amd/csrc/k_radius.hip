@@ -11,6 +11,14 @@
 namespace {
 constexpr int NB = 8194;  // bins 0..8192 = smallest m with d2 < thr[m]; 8193 = beyond max_r
 
+// threshold m of the bisection grid, fp32((5 m / 8192)^2) exactly as the host table d_rad_thr holds it: recomputed (two exact
+// binary64 products, one rounding) instead of loaded -- the two dependent loads per distance were what the kernel waited for
+__device__ __forceinline__ float thr_of(int m)
+{
+    const double r = 5.0 * (double)m / 8192.0;
+    return (float)(r * r);
+}
+
 __global__ __launch_bounds__(256) void radius_hist_kernel(const float* __restrict__ pts, int n_pts,
                                                           const float* __restrict__ kpts, int nk,
                                                           const float* __restrict__ thr, unsigned long long* hist)
@@ -37,8 +45,8 @@ __global__ __launch_bounds__(256) void radius_hist_kernel(const float* __restric
             if (!(d2 <= 25.0f)) continue;  // dists_sqr[dists_sqr <= max_r*max_r]
             int m = (int)(sqrtf(fmaxf(d2, 0.0f)) * 1638.4f);
             m = m < 0 ? 0 : (m > 8192 ? 8192 : m);
-            while (m <= 8192 && !(d2 < thr[m])) ++m;
-            while (m > 0 && d2 < thr[m - 1]) --m;
+            while (m <= 8192 && !(d2 < thr_of(m))) ++m;
+            while (m > 0 && d2 < thr_of(m - 1)) --m;
             atomicAdd(&h[m], 1u);
         }
     }
@@ -101,6 +109,10 @@ int bxk_radius_hist(bx_ctx* c, hipStream_t s, const float* pts, int n_pts, const
 {
     BX_HIP(hipMemsetAsync(c->rad_hist, 0, sizeof(unsigned long long) * NB, s));
     if (n_pts <= 0 || nk <= 0) return BX_OK;
+    // every workgroup ends with a flush of its 8194-bin LDS histogram into the global one (64-bit atomics: 16 M of them = 102 MB of
+    // write traffic per launch for a 64 KB result).  Measured in round 3: cutting the flushes eightfold (8 point slices instead of 64)
+    // DOUBLES the kernel time (317 -> 629 us) -- 4 waves per CU cannot cover the latency of the per-distance bin search; the flush
+    // traffic is not what the kernel waits for, occupancy is.  64 slices stay.
     int gx = (n_pts + 255) / 256;
     if (gx > 64) gx = 64;
     dim3 grid(gx, (nk + 63) / 64);

@@ -72,6 +72,12 @@ class BufferX(nn.Module):
             raise NotImplementedError("bufferx_amd.BufferX implements the inference path only (config.stage == 'test')")
         if config.match.get("pose_estimator", "ransac") not in ("ransac", "kiss_matcher"):
             raise ValueError(f"Unknown pose estimator: {config.match.pose_estimator}")      # models/pose_estimator.py:48
+        if config.match.get("pose_estimator", "ransac") == "kiss_matcher":
+            import warnings
+            warnings.warn("pose_estimator='kiss_matcher': the HIP back-end (k_kiss.hip) restates KISS-Matcher / ROBIN / TEASER++ from the "
+                          "published algorithms; the kiss_matcher package itself was never available to pin it against (implementation "
+                          "constants in oracle/bx_oracle.c are best guesses), so poses and inlier counts may differ from the package's",
+                          RuntimeWarning, stacklevel=2)
         self.Desc = _Desc()
         self.Pose = _Pose()
         self._ctx = None

@@ -145,8 +145,8 @@ int bx_register_pair(bx_ctx *ctx, void *stream, const float *src, int32_t n_src,
  * While a capture is set, bx_register_pair copies (stream-ordered, device to device) the intermediates of ONE scale into
  * caller-owned device buffers; every pointer is nullable.  The per-cloud transients (permuted cloud, patches, voxel features,
  * last conv map) are taken from cloud `cloud` (0 = src, 1 = tgt); the per-scale tensors from both clouds.  The cumulative tensors
- * are copied right after the consensus step of scale `scale`.  T_ransac / T_final: the pose after the last RANSAC call and the
- * returned pose.  A parity test feeds these tensors, a sampled subset at a time, to the oracle stage that consumes them.
+ * are copied right after the consensus step of scale `scale`.  T_ransac: the binary64 pose after the last pose-estimation call (the returned
+ * pose itself is bx_result.pose).  Not available in the latency form (keypoint_tiles > 1: bx_set_capture returns BX_ERR_STATE).  A parity test feeds these tensors, a sampled subset at a time, to the oracle stage that consumes them.
  * bx_set_capture(ctx, NULL) switches the capture off.  The struct is copied; the buffers must stay alive while it is set.      */
 typedef struct bx_capture {
     int32_t scale, cloud;
