@@ -48,17 +48,21 @@ __device__ __forceinline__ void pq_chain(const float* __restrict__ sm, int base,
 }
 
 template <int OT>
-__global__ __launch_bounds__(64 * (64 / OT), 2) void cost_l0_kernel(const float* __restrict__ s_equi, const float* __restrict__ t_equi,
+__global__ __launch_bounds__(64 * (64 / OT), 8) void cost_l0_kernel(const float* __restrict__ s_equi, const float* __restrict__ t_equi,
                                                         const int32_t* __restrict__ s_mids, const int32_t* __restrict__ t_mids,
                                                         const int32_t* __restrict__ m_dev, int max_m, const double* __restrict__ Wp,
                                                         const double* __restrict__ Wq, const float* __restrict__ bias,
                                                         float* __restrict__ out, const int32_t* __restrict__ skip)
 {
     if (skip && *skip) return;
-    __shared__ float sS[32 * SCS];
-    __shared__ float sT[32 * TCS];
-    __shared__ double sP[32 * 64];          // [o][k*20 + e]  = b[o] + P
-    __shared__ double sQ[32 * 64];          // [o][k*18 + l]
+    // LDS: the staged maps (28.4 KB) and, once every chain has finished with them, b + P / Q (32 KB) in the SAME bytes: 32 KB per
+    // workgroup instead of 61 KB, i.e. five resident workgroups per CU -- the chains wait on the scalar weight stream, more waves hide it
+    __shared__ __attribute__((aligned(16))) char smem[32 * 64 * 8 * 2];
+    static_assert(sizeof(float) * 32 * (SCS + TCS) <= sizeof(smem), "maps fit the P / Q bytes");
+    float* sS = reinterpret_cast<float*>(smem);
+    float* sT = sS + 32 * SCS;
+    double* sP = reinterpret_cast<double*>(smem);          // [o][k*20 + e]  = b[o] + P
+    double* sQ = sP + 32 * 64;                              // [o][k*18 + l]
     int m = *m_dev;
     m = m < max_m ? m : max_m;
     const int u = blockIdx.x;
@@ -92,18 +96,20 @@ __global__ __launch_bounds__(64 * (64 / OT), 2) void cost_l0_kernel(const float*
             const int pos = lane < HO * A ? lane : 0;
             const int k = pos / A, e = pos - k * A;
             pq_chain<OT, 5, SW, SCS>(sS, k * SW + e, Wp + (size_t)ot * 32 * 15 * OT, acc);
-            if (lane < HO * A) {
-#pragma unroll
-                for (int j = 0; j < OT; ++j) sP[(ot * OT + j) * 64 + lane] = (double)bias[ot * OT + j] + acc[j];
-            }
         } else {
             const int pos = lane < HO * AO ? lane : 0;
             const int k = pos / AO, l = pos - k * AO;
             pq_chain<OT, 3, A, TCS>(sT, k * A + l, Wq + (size_t)ot * 32 * 9 * OT, acc);
-            if (lane < HO * AO) {
+        }
+        __syncthreads();                    // every chain is done with the maps: their bytes become P / Q
+        if (wave < NTILE) {
+            if (lane < HO * A) {
 #pragma unroll
-                for (int j = 0; j < OT; ++j) sQ[(ot * OT + j) * 64 + lane] = acc[j];
+                for (int j = 0; j < OT; ++j) sP[(ot * OT + j) * 64 + lane] = (double)bias[ot * OT + j] + acc[j];
             }
+        } else if (lane < HO * AO) {
+#pragma unroll
+            for (int j = 0; j < OT; ++j) sQ[(ot * OT + j) * 64 + lane] = acc[j];
         }
     }
     __syncthreads();

@@ -4,13 +4,18 @@
           --bx_register_pair (C pairs in flight)--> pose --evaluate.pack_state--> one float64 row per pair
 
 The reference does all of this serially per pair on the host thread (dataset/threedmatch.py:66-160 -> collate -> model -> metrics).
-Here the files of the next pairs are parsed and uploaded by a native thread, the per-pair preparation runs on its own HIP stream
-while up to `inflight` earlier pairs occupy the GPU, and nothing on the registration streams waits for the host.
+Here the files of the next pairs are parsed and uploaded by a native thread; the per-pair preparation (voxel analysis, down-sampling,
+shuffle, the reference's NumPy draws, uploads) runs in a preparation thread on its own HIP stream and library context, several
+pairs ahead; the registration thread only enqueues bx_register_pair for up to `inflight` pairs and harvests their results.
 
 NumPy's global RNG is consumed by the same calls, in the same order, as dataset/threedmatch.py + models/patch_embedder.py make
 them (analysis subsamples, shuffle of both clouds, the two shuffles of the second down-sampling, the per-scale permutations), so
 a seeded run replays the reference's random choices; the RANSAC seed is one extra draw (Open3D's RANSAC is unseeded upstream)."""
+import collections
+import copy
 import os
+import queue
+import threading
 import time
 
 import numpy as np
@@ -41,16 +46,23 @@ class Runner:
         self.prep_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get('BX_PREP_PRIO', '0')))
         self._pin, self._pin_ev = {}, {}
         self.timers = {k: 0.0 for k in ("wait_prefetch", "voxel_analysis", "down_sample", "shuffle", "second_sampling_rng", "perm_rng",
-                                        "perm_upload", "harvest_wait", "enqueue")}   # host seconds, accumulated over run()
-        self.pre = Preprocessor(self.ctxs[0], max_raw_points, upload=self._upload)   # bx_pre_* has its own workspace in the context
+                                        "perm_upload", "wait_prepared", "harvest_wait", "enqueue")}   # host seconds, accumulated over run()
+        # the preparation thread drives its OWN library context (a bx_ctx is not shared between threads): a minimal configuration,
+        # it only serves bx_pre_* / bx_permute / bx_random_perm
+        pc = copy.deepcopy(cfg)
+        pc.patch.num_fps, pc.patch.num_points_per_patch, pc.patch.num_scales = 16, 16, 1
+        pc.patch.search_radius_thresholds = [5]
+        pc.patch.num_points_radius_estimate = 16
+        pc.test.keypoint_tiles = 0
+        self.prep_ctx = lib.Context(pc, max_points=self.max_points, device=self.device)
+        self.pre = Preprocessor(self.prep_ctx, max_raw_points, upload=self._upload)   # bx_pre_* has its own workspace in the context
         # every device buffer of the loop is allocated ONCE: an allocation under load costs a hipMalloc, i.e. a device-wide wait.
-        # Pair i uses buffer set i % (C + 1): the C pairs before it may still be in flight.
         dev = f"cuda:{self.device}"
         S = int(cfg.patch.num_scales)
         f32, i32 = torch.float32, torch.int32
         self.sets = [dict(src=torch.empty((self.max_points, 3), dtype=f32, device=dev), tgt=torch.empty((self.max_points, 3), dtype=f32, device=dev),
                           perm_s=torch.empty(S * self.max_points, dtype=i32, device=dev), perm_t=torch.empty(S * self.max_points, dtype=i32, device=dev))
-                     for _ in range(self.C + 1)]
+                     for _ in range(2 * self.C + 2)]     # pair i uses set i % (2C + 2): C pairs in flight + C + 2 being prepared
         self.scratch = dict(fds_s=torch.empty((max_raw_points, 3), dtype=f32, device=dev), fds_t=torch.empty((max_raw_points, 3), dtype=f32, device=dev),
                             sds_s=torch.empty((self.max_points, 3), dtype=f32, device=dev), sds_t=torch.empty((self.max_points, 3), dtype=f32, device=dev),
                             idx_s=torch.empty(max_raw_points, dtype=i32, device=dev), idx_t=torch.empty(max_raw_points, dtype=i32, device=dev))
@@ -59,6 +71,7 @@ class Runner:
 
     def close(self):
         self.pf.close()
+        self.prep_ctx.close()
         for c in self.ctxs:
             c.close()
 
@@ -95,7 +108,7 @@ class Runner:
         tm["wait_prefetch"] += time.perf_counter() - t0; t0 = time.perf_counter()
         sphericity = 0.0
         sc = self.scratch
-        c0 = self.ctxs[0]
+        c0 = self.prep_ctx
         dev_rng = self.rng == "device"
         if dev_rng:
             base = int(np.random.randint(0, 2**31 - 1)) << 8          # the ONE host draw of this pair; +k = its k-th device stream
@@ -123,8 +136,8 @@ class Runner:
             self._dev_perms = (bufs["perm_s"][:S * ns_].view(S, ns_), bufs["perm_t"][:S * nt_].view(S, nt_), base + 255)
             tm["shuffle"] += time.perf_counter() - t0
             return src, tgt, bool(cfg.patch.is_aligned_to_global_z), voxel_size, sphericity
-        src = self.ctxs[0].permute(src, self._upload("shuf_s", np.random.permutation(src.shape[0]).astype(np.int32)), out=bufs["src"])
-        tgt = self.ctxs[0].permute(tgt, self._upload("shuf_t", np.random.permutation(tgt.shape[0]).astype(np.int32)), out=bufs["tgt"])
+        src = c0.permute(src, self._upload("shuf_s", np.random.permutation(src.shape[0]).astype(np.int32)), out=bufs["src"])
+        tgt = c0.permute(tgt, self._upload("shuf_t", np.random.permutation(tgt.shape[0]).astype(np.int32)), out=bufs["tgt"])
         tm["shuffle"] += time.perf_counter() - t0; t0 = time.perf_counter()
         if replay_rng:
             # the loader's second down-sampling only feeds training, but its shuffles (and the max_numPts subsample) advance the RNG
@@ -160,11 +173,59 @@ class Runner:
         gids = mine                                   # local position -> global pair index
         pairs = [pairs[i] for i in mine]
         n = len(pairs)
-        depth = min(n, C + 2)
-        tickets = [self.pf.submit(p["src_path"], p["tgt_path"]) for p in pairs[:depth]]
         rows, poses = [None] * n, [None] * n_all
         pending = [None] * C
-        next_draw = 0                                 # global index of the next pair whose host draw has not been consumed
+        NSET = len(self.sets)
+        permits = threading.Semaphore(NSET)           # buffer set i % NSET is free again once pair i - NSET has been harvested
+        ready_q = queue.Queue()
+
+        # ---- the preparation thread: everything of a pair that happens on the host before bx_register_pair -- wait for the prefetched
+        # files, voxel analysis, down-sampling, shuffle, the reference's np.random draws (ONE thread makes all of them, in the
+        # reference's order) and the uploads -- runs up to NSET pairs ahead of the pairs in flight, on its own stream and its own
+        # library context.  The registration thread below only enqueues bx_register_pair and harvests results.
+        def producer():
+            try:
+                depth = min(n, C + 2)
+                tickets = collections.deque(self.pf.submit(p["src_path"], p["tgt_path"]) for p in pairs[:depth])
+                submitted = depth
+                next_draw = 0                         # global index of the next pair whose host draw has not been consumed
+                for i in range(n):
+                    permits.acquire()
+                    if self._stop:
+                        return
+                    t0 = time.perf_counter()
+                    if pair_seed is not None:
+                        np.random.seed((int(pair_seed) + gids[i]) % (2 ** 32))
+                    elif world > 1:
+                        # rng="device": the pairs of the other ranks consume their ONE host draw too (same stream as a single rank)
+                        while next_draw < gids[i]:
+                            np.random.randint(0, 2**31 - 1)
+                            next_draw += 1
+                        next_draw = gids[i] + 1
+                    with t.cuda.stream(self.prep_stream):
+                        bufs = self.sets[i % NSET]
+                        src, tgt, aligned, _, _ = self._prepare(tickets.popleft(), voxel_size, replay_rng, bufs)
+                        tq = time.perf_counter()
+                        if self.rng == "device":
+                            d_ps, d_pt, seed = self._dev_perms
+                        else:
+                            perm_s, perm_t = [], []
+                            for _ in range(S):        # models/patch_embedder.py:96, order scale0-src, scale0-tgt, scale1-src, ...
+                                perm_s.append(np.random.choice(src.shape[0], src.shape[0], replace=False).astype(np.int32))
+                                perm_t.append(np.random.choice(tgt.shape[0], tgt.shape[0], replace=False).astype(np.int32))
+                            seed = int(np.random.randint(0, 2**31 - 1))
+                            self.timers["perm_rng"] += time.perf_counter() - tq; tq = time.perf_counter()
+                            d_ps = self._upload("perm_s", np.stack(perm_s), into=bufs["perm_s"])
+                            d_pt = self._upload("perm_t", np.stack(perm_t), into=bufs["perm_t"])
+                            self.timers["perm_upload"] += time.perf_counter() - tq
+                        ready = t.cuda.Event()
+                        ready.record(self.prep_stream)
+                    if submitted < n:
+                        tickets.append(self.pf.submit(pairs[submitted]["src_path"], pairs[submitted]["tgt_path"]))
+                        submitted += 1
+                    ready_q.put((src, tgt, aligned, d_ps, d_pt, seed, ready, time.perf_counter() - t0))
+            except BaseException as e:                # surfaces in the registration thread
+                ready_q.put(e)
 
         def harvest(c):
             if pending[c] is None:
@@ -185,53 +246,38 @@ class Runner:
                                           r.scales_used, data_s, a.elapsed_time(b) / 1e3, [0.0, 0.0, 0.0],
                                           cfg.test.rte_thresh, cfg.test.rre_thresh)
             pending[c] = None
+            permits.release()
 
-        for i in range(n):
-            t0 = time.perf_counter()
-            if pair_seed is not None:
-                np.random.seed((int(pair_seed) + gids[i]) % (2 ** 32))
-            elif world > 1:
-                # rng="device": the pairs of the other ranks consume their ONE host draw too (same global stream as a single rank)
-                while next_draw < gids[i]:
-                    np.random.randint(0, 2**31 - 1)
-                    next_draw += 1
-                next_draw = gids[i] + 1
-            with t.cuda.stream(self.prep_stream):
-                bufs = self.sets[i % (C + 1)]
-                src, tgt, aligned, _, _ = self._prepare(tickets[i], voxel_size, replay_rng, bufs)
+        self._stop = False
+        th = threading.Thread(target=producer, name="bx-prepare", daemon=True)
+        th.start()
+        try:
+            for i in range(n):
                 tq = time.perf_counter()
-                if self.rng == "device":
-                    d_ps, d_pt, seed = self._dev_perms
-                else:
-                    perm_s, perm_t = [], []
-                    for _ in range(S):        # models/patch_embedder.py:96, order scale0-src, scale0-tgt, scale1-src, ...
-                        perm_s.append(np.random.choice(src.shape[0], src.shape[0], replace=False).astype(np.int32))
-                        perm_t.append(np.random.choice(tgt.shape[0], tgt.shape[0], replace=False).astype(np.int32))
-                    seed = int(np.random.randint(0, 2**31 - 1))
-                    self.timers["perm_rng"] += time.perf_counter() - tq; tq = time.perf_counter()
-                    d_ps = self._upload("perm_s", np.stack(perm_s), into=bufs["perm_s"])
-                    d_pt = self._upload("perm_t", np.stack(perm_t), into=bufs["perm_t"])
-                    self.timers["perm_upload"] += time.perf_counter() - tq
-                ready = t.cuda.Event()
-                ready.record(self.prep_stream)
-            if i + depth < n:
-                tickets.append(self.pf.submit(pairs[i + depth]["src_path"], pairs[i + depth]["tgt_path"]))
-            data_s = time.perf_counter() - t0
-            c = i % C
-            tq = time.perf_counter()
-            harvest(c)
-            self.timers["harvest_wait"] += time.perf_counter() - tq; tq = time.perf_counter()
-            st = self.streams[c]
-            st.wait_event(ready)
-            with t.cuda.stream(st):
-                a, b = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
-                a.record(st)
-                self.ctxs[c].register_pair_async(src, tgt, aligned, d_ps, d_pt, seed, self.results[c])
-                b.record(st)
-            pending[c] = (i, a, b, data_s)
-            self.timers["enqueue"] += time.perf_counter() - tq
-        for c in range(C):
-            harvest(c)
+                item = ready_q.get()
+                if isinstance(item, BaseException):
+                    raise item
+                src, tgt, aligned, d_ps, d_pt, seed, ready, data_s = item
+                self.timers["wait_prepared"] += time.perf_counter() - tq; tq = time.perf_counter()
+                c = i % C
+                harvest(c)
+                self.timers["harvest_wait"] += time.perf_counter() - tq; tq = time.perf_counter()
+                st = self.streams[c]
+                st.wait_event(ready)
+                with t.cuda.stream(st):
+                    a, b = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+                    a.record(st)
+                    self.ctxs[c].register_pair_async(src, tgt, aligned, d_ps, d_pt, seed, self.results[c])
+                    b.record(st)
+                pending[c] = (i, a, b, data_s)
+                self.timers["enqueue"] += time.perf_counter() - tq
+            for c in range(C):
+                harvest(c)
+        finally:
+            self._stop = True
+            for _ in range(NSET + 1):                 # a producer parked on the semaphore wakes up and leaves
+                permits.release()
+            th.join(timeout=60)
         return np.stack(rows) if n else np.zeros((0, evaluate.STATE_W)), poses
 
 

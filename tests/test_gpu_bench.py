@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--num-fps", "256", "--ppp", "128", "--scales", "2", "--distinct", "3", "--inflight", "2", "--warmup", "1", "--no-cpu-baseline"]
+SMALL = ["--num-fps", "256", "--ppp", "128", "--scales", "2", "--distinct", "3", "--inflight", "2", "--warmup", "1", "--no-cpu-baseline", "--e2e-pairs", "4"]
 
 
 def _run(cmd, env_extra, timeout=900):
@@ -44,3 +44,7 @@ def test_world2_records_equal_world1(tmp_path):
         lf = j["p50_ms_per_pair_latency_form"]
         assert lf["results_identical_to_throughput_form"] is True and lf["p50_ms"] > 0 and j["p50_ms_per_pair_inflight1"] > 0
     assert j1["registered_ok"] == j2["registered_ok"] == j3["registered_ok"]
+    assert j1["host_ms_per_pair"] > 0
+    e2e = j1["e2e_pairs_per_s"]          # files -> poses leg (N = 1 only): both RNG modes produce a rate
+    assert e2e.get("device", 0) > 0 and e2e.get("reference", 0) > 0, e2e
+    assert "e2e_pairs_per_s" not in j2
