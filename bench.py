@@ -482,6 +482,8 @@ def e2e_rate(bx, pw, cfg, args, device, hot_value):
             res[mode] = round(n_pairs / dt, 3)
             res[mode + "_detail"] = {"registered_ok": "%d/%d" % (int(rows[:, 1].sum()), n_pairs),
                                      "prepare_thread_ms_per_pair": round(float(np.mean(rows[:, 8])) * 1e3, 2),
+                                     "prepare_thread_breakdown_ms": {k: round(run.timers[k] / n_pairs * 1e3, 2) for k in
+                                                                     ("wait_prefetch", "voxel_analysis", "down_sample", "shuffle", "second_sampling_rng", "perm_rng", "perm_upload")},
                                      "registration_thread_ms_per_pair": {k: round(run.timers[k] / n_pairs * 1e3, 2) for k in ("wait_prepared", "harvest_wait", "enqueue")}}
         res["device_over_hot_path"] = round(res["device"] / hot_value, 3)
         return res
