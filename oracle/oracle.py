@@ -144,6 +144,18 @@ def conv(x, tap, W, bias, relu):
     return out
 
 
+def conv_wino(x, W, bias, relu, ele_n=7, azi_n=20):
+    """Cylindrical 3x3 layer as Winograd F(2x2, 3x3) (bxo_conv_wino).  x [units][n_chunks][ele*azi][16]; W [n_chunks][9][16][cout]."""
+    x, W, bias = _f(x), _f(W), _f(bias)
+    units, n_chunks, p_in, _ = x.shape
+    cout = W.shape[-1]
+    assert p_in == ele_n * azi_n and W.shape == (n_chunks, 9, 16, cout)
+    out = np.zeros((units, (cout + 15) // 16, p_in, 16), np.float32)
+    lib().bxo_conv_wino(_p(x), C.c_int(units), C.c_int(n_chunks), C.c_int(ele_n), C.c_int(azi_n), _p(W), _p(bias), C.c_int(cout),
+                        C.c_int(int(relu)), _p(out))
+    return out
+
+
 def desc_head(x, w1, b1, w2, b2):
     x = _f(x)
     K, _, npos, _ = x.shape
