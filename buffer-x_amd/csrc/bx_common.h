@@ -44,6 +44,7 @@ constexpr int BX_NDESC = 8, BX_NPOSE = 10;
 struct ConvLayerDev {
     float* W;        // B fragments of the 16x16x4 kernels: [chunk*taps][column tile 16][lane][4]
     float* W32;      // B fragments of the 32x32x2 kernels (k_conv32.hip): [chunk*taps][column tile 32][lane][8]; Desc layers only
+    float* Wwino;    // B fragments of the Winograd kernels (k_wino.hip): U = G g G^T, [chunk*16 + plane][column tile 16][lane][4]; Desc layers only
     float* b;        // [cout]
     int32_t* lrow;   // [p_in]  LDS row of an input position inside a unit's p_lds-row slab
     int32_t* lrow2;  // [p_in]  second copy (azimuth wrap halo) or -1
@@ -180,6 +181,8 @@ struct bx_ctx {
     void* pre;                          // bx_pre_ws* (k_pre.hip): workspace of the pre-processing entry points, reserved on demand
     int conv_cap[2][BX_NPOSE];          // persistent-grid size of every conv layer on THIS device (0 = not set up yet)
     int conv32_cap[BX_NDESC];           // the same for the 32x32x2 kernels (k_conv32.hip)
+    int wino_cap[BX_NDESC];             // the same for the Winograd kernels (k_wino.hip)
+    int use_wino;                       // BX_DESC_CONV=winograd: Cylindrical_Net layers as F(2x2, 3x3) Winograd convolutions
     int conv_persist, conv_cap_override, n_cu, use_conv32;
     double *d_cost_wp, *d_cost_wq;      // collapsed CostNet layer 0 (k_cost.hip): binary64 weights of the P / Q convolutions
     int cost_direct;                    // BX_COST_L0=direct: layer 0 as the fp32 MFMA convolution of the implicit volume (cost_l1_kernel)
@@ -217,6 +220,8 @@ int bxk_patch_features(bx_ctx* c, hipStream_t s, const float* patches, int K, in
 int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, const int32_t* units_dev, int max_units,
              float* out);
 int bxk_conv32(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t* units_dev, int max_units, float* out);
+int bxk_wino(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t* units_dev, int max_units, float* out);
+int bxk_wino_weights(const float* w, int nchunk, int cout, float** d_out);
 int bxk_cost_l1(bx_ctx* c, hipStream_t s, const float* s_equi, const float* t_equi, const int32_t* s_mids,
                 const int32_t* t_mids, const int32_t* m_dev, int max_m, float* out);
 int bxk_cost_l0_weights(const float* w0, double** d_wp, double** d_wq);

@@ -558,6 +558,10 @@ int launch_conv(bx_ctx* c, int net, int layer, hipStream_t s, const ConvLayerDev
 int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, const int32_t* units_dev, int max_units, float* out)
 {
     constexpr int CYL = (BX_ELE + 2) * (BX_AZI + 2);   // 198 LDS rows per unit: cylindrical map + halo
+    if (net == 0 && c->use_wino) {
+        const int rcw = bxk_wino(c, s, layer, in, units_dev, max_units, out);
+        if (rcw >= 0) return rcw;
+    }
     if (net == 0 && c->use_conv32) {
         const int rc32 = bxk_conv32(c, s, layer, in, units_dev, max_units, out);
         if (rc32 >= 0) return rc32;

@@ -1,0 +1,339 @@
+// k_wino.hip -- Cylindrical_Net layers as Winograd F(2x2, 3x3) convolutions on the f32 matrix cores (round 3).
+//
+// Same layers as conv_kernel of k_conv.hip (reference models/patchnet.py:49-84; padding utils/common.py:265-310: circular in
+// azimuth, zero in elevation) with 2.25x fewer multiplications (Lavin & Gray 2016): the 7 x 20 map is cut into 4 x 10 output tiles
+// of 2 x 2 (the 8th output row does not exist and is dropped); per tile and channel the 4 x 4 input window d becomes
+// V = B^T d B (additions only), the channel contraction M[xi][nu] = sum_c V[xi][nu][c] U[xi][nu][c][o] is SIXTEEN independent
+// GEMMs (rows = tiles, K = input channels, columns = output channels) on v_mfma_f32_16x16x4_f32, and Y = A^T M A (+ bias, ReLU)
+// folds the sixteen results back into the 2 x 2 outputs.  U = G g G^T is computed on the host in binary64 and rounded once.
+// The arithmetic contract is restated by oracle/bx_oracle.c::bxo_conv_wino; GPU == oracle bit for bit.
+//
+// Workgroup = 8 waves, 64 output channels of ONE unit (patch) at a time: wave (ct, half) owns the column tile ct (16 channels) and
+// the EIGHT planes of rows xi = 2 half, 2 half + 1, for all three 16-row tiles of the 48 (40 used) tile rows: 24 accumulator tiles =
+// 96 VGPRs at two waves per SIMD (256 VGPRs each: room for deep operand prefetch).  The 128-channel layers run two workgroups per
+// unit (blockIdx.y = channel half; both transform the unit's input); the two 32-channel layers stay on the direct kernels.
+// Persistent walk over the units.  Pipeline (ONE barrier per 16-channel chunk): chunks are numbered g = 0, 1, ... across the units of
+// the walk; V(g) lives in plane set g & 1, the slab of chunk g (input with its halo: 10 x 22 rows of 80 B) in slab buffer g & 1.
+// Iteration g: write the slab of chunk g + 2 (fetched one iteration earlier), request chunk g + 3, then -- one wave of every SIMD in
+// one order, the other in the other -- the input transform of chunk g + 1 (thread item = (xi, tile, 4-channel quad): four V planes)
+// and the MFMAs of chunk g (one ds_read_b128 feeds four MFMAs; the B fragment of a plane, one 16-byte load per lane requested a
+// whole chunk ahead, is reused by the three row tiles): while one wave streams MFMAs the other does the transform's VALU / LDS work.
+// Output transform: every wave folds its two rows into r_xi[j] = (M0 + M1) + M2 | (M1 - M2) - M3 lane-locally; the half-0 wave
+// hands r0 + r1 and r1 to the half-1 wave through LDS (bytes of the consumed plane set), which forms Y[0][j] = ((r0 + r1) + r2),
+// Y[1][j] = ((r1 - r2) - r3), adds the bias, applies ReLU and stores.
+// MFMA work per unit and layer: 16 planes x 3 row tiles against 9 taps x 8.75 row tiles of the direct form (0.61x).
+#include "bx_common.h"
+#include <cstdlib>
+#include <vector>
+
+namespace {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int ROWF = 20;                         // floats per LDS row (16 + 4 pad)
+constexpr int WP = BX_AZI + 2;                   // slab columns (wrap-around halo)
+constexpr int HP = BX_ELE + 3;                   // slab rows: h = -1 .. ele_n + 1 (tile row 3 reaches two rows below the map)
+constexpr int SLAB_FLOATS = HP * WP * ROWF;      // 4400
+constexpr int TR = (BX_ELE + 1) / 2, TC = BX_AZI / 2, NT_ = TR * TC;   // 4 x 10 = 40 tiles
+constexpr int VROWS = 48;                        // tile rows per plane, padded to three MFMA row tiles
+constexpr int VPLANE = VROWS * ROWF;             // floats per (xi, nu) plane
+constexpr size_t WINO_LDS = (size_t)(2 * SLAB_FLOATS + 2 * 16 * VPLANE) * 4;   // 2 x 17.6 KB + 2 x 61.4 KB = 158 KB
+constexpr int CW = 64, CT = 512;                 // output channels / threads of a workgroup
+static_assert(WINO_LDS <= 160 * 1024, "double-buffered slab + V planes fit the LDS");
+static_assert(2 * 2 * NT_ * CW <= 16 * VPLANE, "the r exchange fits the bytes of one set of V planes");
+
+template <int NCHUNK, int COUT, bool RELU>
+__global__ __launch_bounds__(CT, 2) void wino_kernel(const float* __restrict__ in, int units, const float* __restrict__ U,
+                                                     const float* __restrict__ bias, float* __restrict__ out,
+                                                     const int32_t* __restrict__ skip)
+{
+    if (skip && *skip) return;
+    constexpr int NT = COUT / 16;
+    constexpr int NPIECE = BX_EA * 4;                          // float4 pieces of one chunk of one unit
+    constexpr int NLD = (NPIECE + CT - 1) / CT;
+    constexpr int NITEM = 4 * NT_ * 4, NIT = (NITEM + CT - 1) / CT;   // transform items (xi, tile, quad) per thread
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* slab0 = reinterpret_cast<float*>(smem);
+    float* V0 = slab0 + 2 * SLAB_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave & 1, ctl = wave >> 1;                // plane rows {2 half, 2 half + 1} / column tile inside the workgroup
+    const int ctg = (int)blockIdx.y * (CW / 16) + ctl;         // column tile of the layer
+    const int li = lane & 15, kk = lane >> 4;
+    const bool mfma_first = ((wave >> 2) & 1) != 0;            // waves w and w + 4 share a SIMD: one of each order on it
+
+    // ---- LDS starts as zeros: the halo rows of the slabs and the 8 padding rows of every plane
+    for (int i = tid; i < (int)(WINO_LDS / 16); i += CT) reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    int my_units = 0;
+    if ((int)blockIdx.x < units) my_units = (units - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
+    if (my_units == 0) return;
+    const int NG = my_units * NCHUNK;
+    auto unit_of = [&](int g) { return (int)blockIdx.x + (g / NCHUNK) * (int)gridDim.x; };
+
+    const float4* in4 = reinterpret_cast<const float4*>(in);
+    float4 st[NLD];
+    auto gload = [&](int g) {
+        const int u = unit_of(g), cc = g % NCHUNK;
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int f = tid + q * CT;
+            st[q] = f < NPIECE ? in4[((size_t)u * NCHUNK + cc) * NPIECE + f] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lwrite = [&](int g) {
+        float* slab = slab0 + (g & 1) * SLAB_FLOATS;
+        int tq = tid;
+        asm volatile("" : "+v"(tq));      // destination addresses are recomputed (pure integer math): fewer live registers
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int f = tq + q * CT;
+            if (f < NPIECE) {
+                const int p = f >> 2, part = f & 3;
+                const int h = p / BX_AZI, w = p - h * BX_AZI;
+                float* d = slab + ((h + 1) * WP + (w + 1)) * ROWF + part * 4;
+                *reinterpret_cast<float4*>(d) = st[q];
+                if (w == 0) *reinterpret_cast<float4*>(d + BX_AZI * ROWF) = st[q];                 // column 20 = column 0
+                else if (w == BX_AZI - 1) *reinterpret_cast<float4*>(d - BX_AZI * ROWF) = st[q];   // column -1 = column 19
+            }
+        }
+    };
+    // transform items of this thread: item = (x, tile, quad); t_x = d[ra] +- d[rb] down the columns, then along the row
+    int ia[NIT], ib[NIT], iv[NIT];
+    float isg[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int it = tid + k * CT;
+        ia[k] = -1; ib[k] = 0; iv[k] = 0; isg[k] = 0.f;
+        if (it < NITEM) {
+            const int x = it / (NT_ * 4), rem = it - x * (NT_ * 4);
+            const int t = rem >> 2, part = rem & 3;
+            const int tr = t / TC, tc = t - tr * TC;
+            const int ra = x == 0 ? 0 : (x == 2 ? 2 : 1);
+            const int rb = x == 0 ? 2 : (x == 1 ? 2 : (x == 2 ? 1 : 3));
+            isg[k] = x == 1 ? 1.0f : -1.0f;                    // fmaf(+-1, b, a) == a +- b exactly
+            ia[k] = ((2 * tr + ra) * WP + 2 * tc) * ROWF + part * 4;
+            ib[k] = ((2 * tr + rb) * WP + 2 * tc) * ROWF + part * 4;
+            iv[k] = (x * 4) * VPLANE + t * ROWF + part * 4;
+        }
+    }
+    auto transform = [&](int g) {                              // chunk g: slab buffer g & 1 -> plane set g & 1
+        const float* slab = slab0 + (g & 1) * SLAB_FLOATS;
+        float* Vp = V0 + (g & 1) * 16 * VPLANE;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            if (ia[k] < 0) continue;
+            const float sg = isg[k];
+            float4 tj[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 a = *reinterpret_cast<const float4*>(slab + ia[k] + j * ROWF);
+                const float4 b = *reinterpret_cast<const float4*>(slab + ib[k] + j * ROWF);
+                tj[j] = make_float4(fmaf(sg, b.x, a.x), fmaf(sg, b.y, a.y), fmaf(sg, b.z, a.z), fmaf(sg, b.w, a.w));
+            }
+            float* vd = Vp + iv[k];
+            *reinterpret_cast<float4*>(vd) = make_float4(tj[0].x - tj[2].x, tj[0].y - tj[2].y, tj[0].z - tj[2].z, tj[0].w - tj[2].w);
+            *reinterpret_cast<float4*>(vd + VPLANE) = make_float4(tj[1].x + tj[2].x, tj[1].y + tj[2].y, tj[1].z + tj[2].z, tj[1].w + tj[2].w);
+            *reinterpret_cast<float4*>(vd + 2 * VPLANE) = make_float4(tj[2].x - tj[1].x, tj[2].y - tj[1].y, tj[2].z - tj[1].z, tj[2].w - tj[1].w);
+            *reinterpret_cast<float4*>(vd + 3 * VPLANE) = make_float4(tj[1].x - tj[3].x, tj[1].y - tj[3].y, tj[1].z - tj[3].z, tj[1].w - tj[3].w);
+        }
+    };
+
+    const int col = ctg * 16 + li;
+    const float bv = bias[col];
+    // B fragments: [chunk * 16 + plane][column tile][lane][4] (the layout of the direct kernels with 16 "taps"); this wave's planes
+    // are half * 8 + 0..7
+    const float4* wbase = reinterpret_cast<const float4*>(U) + ((size_t)(half * 8) * NT + ctg) * 64 + lane;
+    // A operand of row tile rt of plane half*8 + p: row rt*16 + li, slots 4 kk .. 4 kk + 3
+    const int aoff = ((half * 8 * VROWS + li) * ROWF + kk * 4) * 4;
+
+    f32x4 acc[8][3];
+    // the eight B fragments of a chunk are requested one chunk ahead: plane p's fragment of the NEXT chunk right after plane p's MFMAs
+    float4 bring[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) bring[p] = wbase[((size_t)p * NT) * 64];      // chunk 0
+    auto mfma_chunk = [&](int g) {
+        int ccn = g % NCHUNK + 1;
+        ccn = ccn == NCHUNK ? 0 : ccn;                                              // chunk after this one (next unit: chunk 0)
+        const char* abase = reinterpret_cast<const char*>(V0 + (g & 1) * 16 * VPLANE) + aoff;
+        // 24 (plane, row tile) steps, A operand two steps ahead
+        f32x4 a0 = *reinterpret_cast<const f32x4*>(abase);
+        f32x4 a1 = *reinterpret_cast<const f32x4*>(abase + (16 * ROWF) * 4);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const float4 bq = bring[p];
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt) {
+                const int stp = p * 3 + rt + 2;                                      // the step whose operand is requested now
+                f32x4 a2 = a0;
+                if (stp < 24) a2 = *reinterpret_cast<const f32x4*>(abase + (((stp / 3) * VROWS + (stp % 3) * 16) * ROWF) * 4);
+                acc[p][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bq.x, acc[p][rt], 0, 0, 0);
+                acc[p][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bq.y, acc[p][rt], 0, 0, 0);
+                acc[p][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bq.z, acc[p][rt], 0, 0, 0);
+                acc[p][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bq.w, acc[p][rt], 0, 0, 0);
+                a0 = a1; a1 = a2;
+                __builtin_amdgcn_sched_barrier(0);      // pins the order: without it the scheduler hoists every reload of `bring` and every
+                                                        // A read to the top of the chunk and the register demand doubles (spills between the MFMAs)
+            }
+            bring[p] = wbase[((size_t)(ccn * 16 + p) * NT) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- prologue: slabs of chunks 0 and 1, V(0), chunk 2 on its way
+    gload(0);
+    __syncthreads();                 // zero fill complete
+    lwrite(0);
+    if (NG > 1) { gload(1); lwrite(1); }
+    __syncthreads();
+    transform(0);
+    if (NG > 2) gload(2);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int g = 0; g < NG; ++g) {
+        const int cc = g % NCHUNK;
+        if (cc == 0) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+#pragma unroll
+                for (int rt = 0; rt < 3; ++rt) acc[p][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (g + 2 < NG) lwrite(g + 2);          // slab buffer g & 1: chunk g was transformed in the previous iteration
+        if (g + 3 < NG) gload(g + 3);
+        // ONE copy of the MFMA code (two copies make the accumulators change registers between them: twice the VGPRs)
+        if (!mfma_first && g + 1 < NG) transform(g + 1);
+        mfma_chunk(g);
+        if (mfma_first && g + 1 < NG) transform(g + 1);
+        __syncthreads();             // V(g + 1) and the slab of chunk g + 2 complete; plane set g & 1 is free
+        if (cc != NCHUNK - 1) continue;
+        // ---- output transform of the unit.  Lane (li, kk) of wave (ct, half) holds M[xi][0..3] (xi = 2 half, 2 half + 1) of tiles
+        //      rt*16 + 4 kk + r and channel `col`: r_xi[0] = (M0 + M1) + M2, r_xi[1] = (M1 - M2) - M3.  half 0 hands r0 + r1 and r1 to
+        //      half 1 through LDS [which][j][tile][CW] (the bytes of plane set g & 1, untouched by the next transform until the barriers)
+        const int u = unit_of(g);
+        float* ex = V0 + (g & 1) * 16 * VPLANE;
+        int kko = kk, lio = ctl * 16 + li;
+        asm volatile("" : "+v"(kko), "+v"(lio));   // keeps the exchange / store addresses out of loop-invariant hoisting
+        if (half == 0) {
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = rt * 16 + kko * 4 + r;
+                    if (t < NT_) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const float ra = j == 0 ? (acc[0][rt][r] + acc[1][rt][r]) + acc[2][rt][r] : (acc[1][rt][r] - acc[2][rt][r]) - acc[3][rt][r];
+                            const float rb = j == 0 ? (acc[4][rt][r] + acc[5][rt][r]) + acc[6][rt][r] : (acc[5][rt][r] - acc[6][rt][r]) - acc[7][rt][r];
+                            ex[((0 * 2 + j) * NT_ + t) * CW + lio] = ra + rb;      // r0 + r1
+                            ex[((1 * 2 + j) * NT_ + t) * CW + lio] = rb;           // r1
+                        }
+                    }
+                }
+        }
+        __syncthreads();
+        if (half == 1) {
+            float* ou = out + ((size_t)u * NT + ctg) * BX_EA * 16 + (4 * (li & 3) + (li >> 2));
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = rt * 16 + kko * 4 + r;
+                    if (t < NT_) {
+                        const int tr = t / TC, tc = t - tr * TC;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const float r2 = j == 0 ? (acc[0][rt][r] + acc[1][rt][r]) + acc[2][rt][r] : (acc[1][rt][r] - acc[2][rt][r]) - acc[3][rt][r];
+                            const float r3 = j == 0 ? (acc[4][rt][r] + acc[5][rt][r]) + acc[6][rt][r] : (acc[5][rt][r] - acc[6][rt][r]) - acc[7][rt][r];
+                            const float s01 = ex[((0 * 2 + j) * NT_ + t) * CW + lio];
+                            const float r1 = ex[((1 * 2 + j) * NT_ + t) * CW + lio];
+                            float y0 = (s01 + r2) + bv;
+                            float y1 = ((r1 - r2) - r3) + bv;
+                            if (RELU) { y0 = y0 > 0.0f ? y0 : 0.0f; y1 = y1 > 0.0f ? y1 : 0.0f; }
+                            const int w = 2 * tc + j;
+                            ou[((2 * tr) * BX_AZI + w) * 16] = y0;
+                            if (2 * tr + 1 < BX_ELE) ou[((2 * tr + 1) * BX_AZI + w) * 16] = y1;
+                        }
+                    }
+                }
+        }
+        __syncthreads();             // the exchange bytes become V planes again (their padding rows may hold exchange data now:
+                                     // rows 40..47 feed accumulator rows that are never stored)
+    }
+}
+
+template <int NCHUNK, int COUT, bool RELU>
+int launch_wino(bx_ctx* c, int layer, hipStream_t s, const ConvLayerDev& L, const float* in, int units, float* out)
+{
+    static_assert(COUT % CW == 0, "a workgroup covers 64 output channels");
+    if (L.nchunk != NCHUNK || L.cout != COUT || (L.relu != 0) != RELU || !L.Wwino) {
+        bx_set_error("winograd layer %d: geometry mismatch (%d chunks, %d channels)", layer, L.nchunk, L.cout);
+        return BX_ERR_STATE;
+    }
+    auto k = wino_kernel<NCHUNK, COUT, RELU>;
+    int& cap = c->wino_cap[layer];
+    if (cap == 0) {
+        BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS));
+        int occ = 0;
+        BX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, CT, WINO_LDS));
+        cap = (occ >= 1 ? occ : 1) * c->n_cu / (COUT / CW);
+        if (cap < 1) cap = 1;
+        if (c->conv_cap_override > 0 && c->conv_cap_override < cap) cap = c->conv_cap_override;
+    }
+    int grid = units < cap ? units : cap;
+    if (grid <= 0) return BX_OK;
+    hipLaunchKernelGGL(k, dim3(grid, COUT / CW), dim3(CT), WINO_LDS, s, in, units, L.Wwino, L.b, out, c->skip);
+    BX_LAUNCH_CHECK();
+    return BX_OK;
+}
+}  // namespace
+
+// U = G g G^T of every (chunk, channel, output channel) in binary64, rounded once (the same expressions as the oracle's
+// wino_filter), packed as B fragments [chunk * 16 + plane][column tile][lane = kk*16 + li][4], element i = U[plane][chunk][kk + 4 i][col]
+int bxk_wino_weights(const float* w /* [nchunk][9][16][cout] */, int nchunk, int cout, float** d_out)
+{
+    const int nt = cout / 16;
+    std::vector<float> frag((size_t)nchunk * 16 * nt * 64 * 4, 0.0f);
+    for (int cc = 0; cc < nchunk; ++cc)
+        for (int ch = 0; ch < 16; ++ch)
+            for (int o = 0; o < cout; ++o) {
+                double g[3][3], Gg[4][3];
+                for (int kh = 0; kh < 3; ++kh)
+                    for (int kw = 0; kw < 3; ++kw) g[kh][kw] = (double)w[(((size_t)cc * 9 + kh * 3 + kw) * 16 + ch) * cout + o];
+                for (int kw = 0; kw < 3; ++kw) {
+                    Gg[0][kw] = g[0][kw];
+                    Gg[1][kw] = 0.5 * ((g[0][kw] + g[1][kw]) + g[2][kw]);
+                    Gg[2][kw] = 0.5 * ((g[0][kw] - g[1][kw]) + g[2][kw]);
+                    Gg[3][kw] = g[2][kw];
+                }
+                for (int xi = 0; xi < 4; ++xi) {
+                    double uu[4];
+                    uu[0] = Gg[xi][0];
+                    uu[1] = 0.5 * ((Gg[xi][0] + Gg[xi][1]) + Gg[xi][2]);
+                    uu[2] = 0.5 * ((Gg[xi][0] - Gg[xi][1]) + Gg[xi][2]);
+                    uu[3] = Gg[xi][2];
+                    for (int nu = 0; nu < 4; ++nu) {
+                        const int pl = xi * 4 + nu, kk = ch & 3, i = ch >> 2, t = o / 16, li = o % 16;
+                        frag[((((size_t)(cc * 16 + pl) * nt + t) * 4 + kk) * 16 + li) * 4 + i] = (float)uu[nu];
+                    }
+                }
+            }
+    BX_HIP(hipMalloc(reinterpret_cast<void**>(d_out), frag.size() * sizeof(float)));
+    BX_HIP(hipMemcpy(*d_out, frag.data(), frag.size() * sizeof(float), hipMemcpyHostToDevice));
+    return BX_OK;
+}
+
+// layer of Cylindrical_Net in the Winograd form; returns -1 when this layer / unit count is not served (caller falls back)
+int bxk_wino(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t* units_dev, int max_units, float* out)
+{
+    if (units_dev || max_units < 1) return -1;
+    const ConvLayerDev& L = c->desc[layer];
+    switch (layer) {
+        case 0: return launch_wino<3, 64, true>(c, layer, s, L, in, max_units, out);
+        case 1: return launch_wino<4, 64, true>(c, layer, s, L, in, max_units, out);
+        case 2: return launch_wino<4, 128, true>(c, layer, s, L, in, max_units, out);
+        case 3: return launch_wino<8, 128, true>(c, layer, s, L, in, max_units, out);
+        case 4: return launch_wino<8, 64, true>(c, layer, s, L, in, max_units, out);
+        case 5: return launch_wino<4, 64, true>(c, layer, s, L, in, max_units, out);
+        // layers 6 and 7 (32 output channels: half a workgroup) stay on the direct kernels
+    }
+    return -1;
+}

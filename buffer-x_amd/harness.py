@@ -43,8 +43,8 @@ class Runner:
         self.results = [c.new_result() for c in self.ctxs]
         # high priority: the preparation kernels are tiny and the host waits for three of their results per pair; they must not
         # queue behind the convolution kernels of the pairs in flight
-        self.prep_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get('BX_PREP_PRIO', '0')))
-        self._pin, self._pin_ev = {}, {}
+        self.prep_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get('BX_PREP_PRIO', '-1')))
+        self._pin, self._pin_ev, self._pin_turn = {}, {}, {}
         self.timers = {k: 0.0 for k in ("wait_prefetch", "voxel_analysis", "down_sample", "shuffle", "second_sampling_rng", "perm_rng",
                                         "perm_upload", "wait_prepared", "harvest_wait", "enqueue")}   # host seconds, accumulated over run()
         # the preparation thread drives its OWN library context (a bx_ctx is not shared between threads): a minimal configuration,
@@ -79,12 +79,16 @@ class Runner:
         """host array -> device through a reusable pinned staging buffer (a pageable source makes the copy synchronous)"""
         t = self.torch
         arr = np.ascontiguousarray(arr)
-        buf = self._pin.get(key)
+        # two staging buffers per key, used alternately: the wait below is for the copy issued two uploads ago, not for the one that
+        # may still sit behind this pair's preparation kernels on the stream
+        self._pin_turn[key] = turn = 1 - self._pin_turn.get(key, 1)
+        pkey, key_ev = (key, turn), (key, turn)
+        buf = self._pin.get(pkey)
         if buf is None or buf.numel() < arr.size or buf.dtype != t.from_numpy(arr).dtype:
             buf = t.empty(max(arr.size, 1), dtype=t.from_numpy(arr).dtype).pin_memory()
-            self._pin[key] = buf
+            self._pin[pkey] = buf
         else:
-            self._pin_ev[key].synchronize()              # the previous copy out of this buffer has completed
+            self._pin_ev[key_ev].synchronize()           # the previous copy out of this buffer has completed
         view = buf[:arr.size].view(arr.shape) if arr.size else buf[:0]
         view.copy_(t.from_numpy(arr))
         dbuf = self._devbuf.get(key) if into is None else into
@@ -95,7 +99,7 @@ class Runner:
         dev.copy_(view, non_blocking=True)
         ev = t.cuda.Event()
         ev.record(t.cuda.current_stream(self.device))
-        self._pin_ev[key] = ev
+        self._pin_ev[key_ev] = ev
         return dev
 
     # ------------------------------------------------------------------------------------------ per-pair preparation

@@ -156,6 +156,19 @@ def conv_wino(x, W, bias, relu, ele_n=7, azi_n=20):
     return out
 
 
+# which restatement of the Cylindrical_Net layers the chain and the tests use -- it follows the product's switch (BX_DESC_CONV,
+# read by bx_create): "direct" = fmaf chain over chunk > tap > channel (conv_kernel, k_conv.hip), "winograd" = bxo_conv_wino (k_wino.hip)
+DESC_CONV = os.environ.get("BX_DESC_CONV", "direct")
+
+
+def desc_conv(x, tap, W, bias, relu):
+    """One Cylindrical_Net layer in the arithmetic the product is configured for (k_wino.hip serves the layers with >= 64 output
+    channels; the two 32-channel layers stay on the direct kernels in either mode)."""
+    if DESC_CONV == "winograd" and np.asarray(W).shape[-1] >= 64:
+        return conv_wino(x, W, bias, relu)
+    return conv(x, tap, W, bias, relu)
+
+
 def desc_head(x, w1, b1, w2, b2):
     x = _f(x)
     K, _, npos, _ = x.shape

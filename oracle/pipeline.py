@@ -13,9 +13,6 @@ from . import oracle as O
 # which restatement of CostNet layer 0 the chain uses: "direct" = fp32 convolution of the materialised cost volume (the contract of
 # cost_l1_kernel), "collapsed" = bxo_cost_l0 (binary64 P - Q form)
 COST_L0 = os.environ.get("BX_ORACLE_COST_L0", "collapsed")
-# restatement of the Cylindrical_Net layers: "direct" = fmaf chain over chunk > tap > channel (conv_kernel of k_conv.hip),
-# "winograd" = bxo_conv_wino (F(2x2, 3x3), k_wino.hip)
-DESC_CONV = os.environ.get("BX_ORACLE_DESC_CONV", "direct")
 
 
 def _w():
@@ -33,10 +30,7 @@ def desc_forward(cloud, kpts, des_r, aligned, perm, pw, cfg, cap=None, tag=""):
     tap = W.cyl_tap_table(cfg.patch.ele_n, cfg.patch.azi_n)
     x = feat
     for L in pw["desc"]:
-        if DESC_CONV == "winograd":
-            x = O.conv_wino(x, L["W"], L["b"], L["relu"], cfg.patch.ele_n, cfg.patch.azi_n)
-        else:
-            x = O.conv(x, tap, L["W"], L["b"], L["relu"])
+        x = O.desc_conv(x, tap, L["W"], L["b"], L["relu"])     # direct or Winograd form, whichever the product runs (BX_DESC_CONV)
     desc, equi = O.desc_head(x, pw["pool_w1"], pw["pool_b1"], pw["pool_w2"], pw["pool_b2"])
     if cap is not None:
         cap[tag + "idx"] = idx

@@ -137,7 +137,7 @@ def test_headline_descriptor_chain(headline, oracle, packed, bx, ri):
     tap = W.cyl_tap_table(cfg.patch.ele_n, cfg.patch.azi_n)
     x = g_feat
     for L in packed["desc"]:
-        x = oracle.conv(x, tap, L["W"], L["b"], L["relu"])
+        x = oracle.desc_conv(x, tap, L["W"], L["b"], L["relu"])
     g_x = lib.chunked_to_logical(_np(cap["x"][tsel]))
     assert np.array_equal(g_x, x)
     # head
@@ -303,7 +303,7 @@ def test_conv_layers_group_walk(bx, packed, oracle, monkeypatch):
                 sel = np.sort(rng.choice(units, NSAMP, replace=False))
                 sel[-1] = units - 1                                   # the ragged tail group
                 ts = torch.as_tensor(sel, device=x.device)
-                ref = oracle.conv(lib.chunked_to_logical(_np(x[ts])), tap, L["W"], L["b"], L["relu"])
+                ref = oracle.desc_conv(lib.chunked_to_logical(_np(x[ts])), tap, L["W"], L["b"], L["relu"])
                 assert np.array_equal(lib.chunked_to_logical(_np(y[ts])), ref), ("desc", l, cap_env)
                 x = y
             if cap_env is None or conv32 == "1":

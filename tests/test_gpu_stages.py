@@ -218,7 +218,7 @@ def test_desc_conv_layer_exact(ctx, oracle, bx, packed, layer):
     units = 11   # not a multiple of the units-per-workgroup: exercises the tail
     x = rng.standard_normal((units, nch, 140, 16)).astype(np.float32)
     x[rng.random(x.shape) < 0.3] = 0
-    ref = oracle.conv(x, bx.weights.cyl_tap_table(), L["W"], L["b"], L["relu"])
+    ref = oracle.desc_conv(x, bx.weights.cyl_tap_table(), L["W"], L["b"], L["relu"])
     out = ctx.conv_layer(0, layer, lib.logical_to_chunked(x), ref.shape)
     assert np.array_equal(lib.chunked_to_logical(_np(out)), ref)
 
@@ -245,7 +245,7 @@ def test_desc_net(ctx, oracle, bx, packed):
     feat = np.abs(rng.standard_normal((K, 3, 140, 16))).astype(np.float32)
     x = feat
     for L in packed["desc"]:
-        x = oracle.conv(x, bx.weights.cyl_tap_table(), L["W"], L["b"], L["relu"])
+        x = oracle.desc_conv(x, bx.weights.cyl_tap_table(), L["W"], L["b"], L["relu"])
     rdesc, requi = oracle.desc_head(x, packed["pool_w1"], packed["pool_b1"], packed["pool_w2"], packed["pool_b2"])
     desc, equi, xo = ctx.desc_net(lib.logical_to_chunked(feat), want_x=True)
     assert np.array_equal(lib.chunked_to_logical(_np(xo)), x)
