@@ -389,8 +389,11 @@ static int create_impl(bx_ctx* c, int device_id)
         // at ~90 % matrix-pipe occupancy and the chip lowers its clock as the occupancy rises), the 16x16x4 form is the default.
         e = getenv("BX_CONV32");
         c->use_conv32 = (e && atoi(e) != 0) ? 1 : 0;
+        // Cylindrical_Net layers with >= 64 output channels: Winograd F(2x2, 3x3) (k_wino.hip, the default: 0.61x the MFMA work of the
+        // direct form) or BX_DESC_CONV=direct (conv_kernel of k_conv.hip).  The two forms have different arithmetic contracts
+        // (oracle: bxo_conv_wino / bxo_conv); oracle/oracle.py follows the same variable.
         e = getenv("BX_DESC_CONV");
-        c->use_wino = (e && strcmp(e, "winograd") == 0) ? 1 : 0;
+        c->use_wino = (e && strcmp(e, "direct") == 0) ? 0 : 1;
         e = getenv("BX_COST_L0");
         c->cost_direct = (e && strcmp(e, "direct") == 0) ? 1 : 0;
     }

@@ -157,8 +157,8 @@ def conv_wino(x, W, bias, relu, ele_n=7, azi_n=20):
 
 
 # which restatement of the Cylindrical_Net layers the chain and the tests use -- it follows the product's switch (BX_DESC_CONV,
-# read by bx_create): "direct" = fmaf chain over chunk > tap > channel (conv_kernel, k_conv.hip), "winograd" = bxo_conv_wino (k_wino.hip)
-DESC_CONV = os.environ.get("BX_DESC_CONV", "direct")
+# read by bx_create): "winograd" (default) = bxo_conv_wino (k_wino.hip), "direct" = fmaf chain over chunk > tap > channel (conv_kernel, k_conv.hip)
+DESC_CONV = os.environ.get("BX_DESC_CONV", "winograd")
 
 
 def desc_conv(x, tap, W, bias, relu):
