@@ -18,9 +18,9 @@
 // one order, the other in the other -- the input transform of chunk g + 1 (thread item = (xi, tile, 4-channel quad): four V planes)
 // and the MFMAs of chunk g (one ds_read_b128 feeds four MFMAs; the B fragment of a plane, one 16-byte load per lane requested a
 // whole chunk ahead, is reused by the three row tiles): while one wave streams MFMAs the other does the transform's VALU / LDS work.
-// Output transform: every wave folds its two rows into r_xi[j] = (M0 + M1) + M2 | (M1 - M2) - M3 lane-locally; the half-0 wave
-// hands r0 + r1 and r1 to the half-1 wave through LDS (bytes of the consumed plane set), which forms Y[0][j] = ((r0 + r1) + r2),
-// Y[1][j] = ((r1 - r2) - r3), adds the bias, applies ReLU and stores.
+// Output transform: every wave folds its two rows into r_xi[j] = (M0 + M1) + M2 | (M1 - M2) - M3 lane-locally; the two halves swap
+// what the other needs for ITS half of the tile rows through LDS (bytes of the consumed plane set) -- half 0: r0 + r1 and r1,
+// half 1: r2 and r3 -- and each forms Y[0][j] = ((r0 + r1) + r2), Y[1][j] = ((r1 - r2) - r3), adds the bias, applies ReLU and stores.
 // MFMA work per unit and layer: 16 planes x 3 row tiles against 9 taps x 8.75 row tiles of the direct form (0.61x).
 #include "bx_common.h"
 #include <cstdlib>
@@ -212,39 +212,45 @@ __global__ __launch_bounds__(CT, 2) void wino_kernel(const float* __restrict__ i
         float* ex = V0 + (g & 1) * 16 * VPLANE;
         int kko = kk, lio = ctl * 16 + li;
         asm volatile("" : "+v"(kko), "+v"(lio));   // keeps the exchange / store addresses out of loop-invariant hoisting
-        if (half == 0) {
+        // both halves fold their two rows; rows r = 2, 3 of every row tile are finished by half 1, rows r = 0, 1 by half 0: each half
+        // hands the other what it needs for the other's rows -- half 0: (r0 + r1, r1), half 1: (r2, r3) -- and stores its own
+        float fa[3][2][2], fb[3][2][2];            // [rt][r within the own pair][j]: half 0: (r0 + r1, r1); half 1: (r2, r3)
 #pragma unroll
-            for (int rt = 0; rt < 3; ++rt)
+        for (int rt = 0; rt < 3; ++rt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int t = rt * 16 + kko * 4 + r;
-                    if (t < NT_) {
+            for (int r = 0; r < 4; ++r) {
+                const int t = rt * 16 + kko * 4 + r;
+                const bool mine = (r >> 1) == half;                 // this half stores rows r = 2 half, 2 half + 1
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const float ra = j == 0 ? (acc[0][rt][r] + acc[1][rt][r]) + acc[2][rt][r] : (acc[1][rt][r] - acc[2][rt][r]) - acc[3][rt][r];
-                            const float rb = j == 0 ? (acc[4][rt][r] + acc[5][rt][r]) + acc[6][rt][r] : (acc[5][rt][r] - acc[6][rt][r]) - acc[7][rt][r];
-                            ex[((0 * 2 + j) * NT_ + t) * CW + lio] = ra + rb;      // r0 + r1
-                            ex[((1 * 2 + j) * NT_ + t) * CW + lio] = rb;           // r1
-                        }
+                for (int j = 0; j < 2; ++j) {
+                    const float ra = j == 0 ? (acc[0][rt][r] + acc[1][rt][r]) + acc[2][rt][r] : (acc[1][rt][r] - acc[2][rt][r]) - acc[3][rt][r];
+                    const float rb = j == 0 ? (acc[4][rt][r] + acc[5][rt][r]) + acc[6][rt][r] : (acc[5][rt][r] - acc[6][rt][r]) - acc[7][rt][r];
+                    const float v0 = half == 0 ? ra + rb : ra;      // half 0: r0 + r1 | half 1: r2
+                    const float v1 = rb;                            // half 0: r1      | half 1: r3
+                    if (mine) { fa[rt][r & 1][j] = v0; fb[rt][r & 1][j] = v1; }
+                    else if (t < NT_) {
+                        ex[((0 * 2 + j) * NT_ + t) * CW + lio] = v0;
+                        ex[((1 * 2 + j) * NT_ + t) * CW + lio] = v1;
                     }
                 }
-        }
+            }
         __syncthreads();
-        if (half == 1) {
+        {
             float* ou = out + ((size_t)u * NT + ctg) * BX_EA * 16 + (4 * (li & 3) + (li >> 2));
 #pragma unroll
             for (int rt = 0; rt < 3; ++rt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int t = rt * 16 + kko * 4 + r;
+                for (int rp = 0; rp < 2; ++rp) {
+                    const int t = rt * 16 + kko * 4 + 2 * half + rp;
                     if (t < NT_) {
                         const int tr = t / TC, tc = t - tr * TC;
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            const float r2 = j == 0 ? (acc[0][rt][r] + acc[1][rt][r]) + acc[2][rt][r] : (acc[1][rt][r] - acc[2][rt][r]) - acc[3][rt][r];
-                            const float r3 = j == 0 ? (acc[4][rt][r] + acc[5][rt][r]) + acc[6][rt][r] : (acc[5][rt][r] - acc[6][rt][r]) - acc[7][rt][r];
-                            const float s01 = ex[((0 * 2 + j) * NT_ + t) * CW + lio];
-                            const float r1 = ex[((1 * 2 + j) * NT_ + t) * CW + lio];
+                            const float x0 = ex[((0 * 2 + j) * NT_ + t) * CW + lio], x1 = ex[((1 * 2 + j) * NT_ + t) * CW + lio];
+                            const float s01 = half == 0 ? fa[rt][rp][j] : x0;      // r0 + r1
+                            const float r1 = half == 0 ? fb[rt][rp][j] : x1;
+                            const float r2 = half == 0 ? x0 : fa[rt][rp][j];
+                            const float r3 = half == 0 ? x1 : fb[rt][rp][j];
                             float y0 = (s01 + r2) + bv;
                             float y1 = ((r1 - r2) - r3) + bv;
                             if (RELU) { y0 = y0 > 0.0f ? y0 : 0.0f; y1 = y1 > 0.0f ? y1 : 0.0f; }

@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/r3h; rm -rf $OUT; mkdir -p $OUT
-export BX_DESC_CONV=winograd
+export BX_DESC_CONV=winograd   # the default since round 3
 timeout 600 python -m pytest tests/test_gpu_stages.py -x -q -k "desc_conv_layer or desc_net" 2>&1 | tail -4
 timeout 1500 python -m pytest tests/test_gpu_headline.py -x -q -k "group_walk or descriptor_chain or vs_reference" 2>&1 | tail -4
 CMD="python bench.py --steps 16 --warmup 4 --no-cpu-baseline --latency-tiles 0 --e2e-pairs 0"
