@@ -144,3 +144,42 @@ def test_kiss_solve_gnc_iterates_and_degenerate_inputs():
     line = np.stack([np.linspace(0, 5, 50), np.zeros(50), np.zeros(50)], 1).astype(np.float32)
     T, info = O.kiss_solve(line, line + np.float32(1.0), np.arange(50, dtype=np.int32), 0.3)
     assert np.isfinite(T).all()
+
+
+# ------------------------------------------------------------------ round 3: the two re-associated stages against their direct forms
+def test_winograd_layers_close_to_direct_form(oracle, bx, packed):
+    """bxo_conv_wino (F(2x2, 3x3), the contract of k_wino.hip) against bxo_conv on the cylindrical tap table, every layer of
+    Cylindrical_Net on post-ReLU-like inputs: same layer up to the re-association (<= 2e-5 absolute on values of O(5)); elevation
+    padding, azimuth wrap-around and the dropped 8th output row are covered by comparing ALL 140 positions."""
+    rng = np.random.default_rng(0)
+    tap = bx.weights.cyl_tap_table()
+    x = np.abs(rng.standard_normal((3, 3, 140, 16))).astype(np.float32)
+    for L in packed["desc"]:
+        a = oracle.conv(x, tap, L["W"], L["b"], L["relu"])
+        b = oracle.conv_wino(x, L["W"], L["b"], L["relu"])
+        assert a.shape == b.shape and np.abs(a - b).max() < 2e-5 * max(1.0, float(np.abs(a).max()))
+        x = a
+    # a map that is non-zero in ONE cell: every tile / window position of the transform is hit by some shift of it
+    L = packed["desc"][1]
+    for p in (0, 19, 20, 79, 120, 139):
+        x = np.zeros((1, 4, 140, 16), np.float32)
+        x[0, :, p, :] = 1.0
+        assert np.abs(oracle.conv(x, tap, L["W"], L["b"], True) - oracle.conv_wino(x, L["W"], L["b"], True)).max() < 1e-5
+
+
+def test_collapsed_cost_layer_close_to_direct_form(oracle, bx, packed):
+    """bxo_cost_l0 (binary64 P - Q form, the contract of k_cost.hip) against the fp32 convolution of the materialised cost volume
+    (CostVolume.forward + the first Conv3d, models/BUFFERX.py:59-65, models/patchnet.py:196), incl. nearly equal maps (P - Q cancels)."""
+    rng = np.random.default_rng(1)
+    K, m = 12, 9
+    se = rng.standard_normal((K, 140, 32)).astype(np.float32)
+    te = rng.standard_normal((K, 140, 32)).astype(np.float32)
+    te[:4] = se[:4] + 1e-3 * rng.standard_normal((4, 140, 32)).astype(np.float32)
+    sm = np.arange(m, dtype=np.int32)
+    tm = np.r_[np.arange(4), rng.permutation(K)[:m - 4]].astype(np.int32)
+    L0 = packed["pose"][0]
+    tap, _ = bx.weights.valid_tap_table((20, 5, 20), (3, 3, 3))
+    direct = oracle.conv(oracle.cost_volume(se, te, sm, tm), tap, L0["W"], L0["b"], True)
+    coll = oracle.cost_l0(se, te, sm, tm, L0["W"], L0["b"])
+    assert direct.shape == coll.shape == (m, 2, 972, 16)
+    assert np.abs(direct - coll).max() < 3e-5 * max(1.0, float(np.abs(direct).max()))
