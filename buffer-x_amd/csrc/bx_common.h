@@ -182,6 +182,8 @@ struct bx_ctx {
     int conv_cap[2][BX_NPOSE];          // persistent-grid size of every conv layer on THIS device (0 = not set up yet)
     int conv32_cap[BX_NDESC];           // the same for the 32x32x2 kernels (k_conv32.hip)
     int wino_cap[BX_NDESC];             // the same for the Winograd kernels (k_wino.hip)
+    int wino_pose_cap[BX_NPOSE];
+    int use_wino_pose;                  // BX_POSE_CONV != direct: CostNet layers 1..5 as valid Winograd convolutions
     int use_wino;                       // BX_DESC_CONV=winograd: Cylindrical_Net layers as F(2x2, 3x3) Winograd convolutions
     int conv_persist, conv_cap_override, n_cu, use_conv32;
     double *d_cost_wp, *d_cost_wq;      // collapsed CostNet layer 0 (k_cost.hip): binary64 weights of the P / Q convolutions
@@ -221,7 +223,8 @@ int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, cons
              float* out);
 int bxk_conv32(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t* units_dev, int max_units, float* out);
 int bxk_wino(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t* units_dev, int max_units, float* out);
-int bxk_wino_weights(const float* w, int nchunk, int cout, float** d_out);
+int bxk_wino_weights(const float* w, int nchunk, int fold, int cout, float** d_out);
+int bxk_wino_pose(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t* units_dev, int max_units, float* out);
 int bxk_cost_l1(bx_ctx* c, hipStream_t s, const float* s_equi, const float* t_equi, const int32_t* s_mids,
                 const int32_t* t_mids, const int32_t* m_dev, int max_m, float* out);
 int bxk_cost_l0_weights(const float* w0, double** d_wp, double** d_wq);

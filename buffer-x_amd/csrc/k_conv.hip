@@ -587,6 +587,10 @@ int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, cons
             case 7: return launch_conv<2, 9, 140, CYL, 140, 32, 2, false>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
         }
     } else if (net == 1) {
+        if (c->use_wino_pose) {
+            const int rcw = bxk_wino_pose(c, s, layer, in, units_dev, max_units, out);
+            if (rcw >= 0) return rcw;
+        }
         const ConvLayerDev& L = c->pose[layer];
         switch (layer) {
             case 1: return launch_conv<2, 27, 972, 972, 256, 64, 1, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);

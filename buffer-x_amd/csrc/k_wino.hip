@@ -290,20 +290,265 @@ int launch_wino(bx_ctx* c, int layer, hipStream_t s, const ConvLayerDev& L, cons
     BX_LAUNCH_CHECK();
     return BX_OK;
 }
+// ---------------------------------------------------------------------------------------------------- CostNet layers 1..5
+// CostNet's layers 1..5 (models/patchnet.py:197-201: k(3,3,3) on [18][3][18], then k(3,1,3) on [16][1][16] .. [10][1][10], un-padded)
+// are 2-D valid 3x3 convolutions over (n, l); layer 1 folds its three k rows into the channel dimension (6 effective chunks
+// e = chunk * 3 + k).  Same transform, same wave roles and output exchange as wino_kernel; differences: valid geometry (a D x D slab
+// without halo, ((D - 2) / 2)^2 tiles per unit), G units per workgroup so that the tile rows fill 3-4 MFMA row tiles whatever the map
+// size (G = 1, 1, 1, 2, 4 for D = 18 .. 10), the unit count is a device-side value (mutual matches of the scale), and -- as the
+// transform and the MFMAs of different waves do not overlap on this chip anyway (every non-MFMA instruction costs matrix-pipe
+// time: the double-buffered pipeline of wino_kernel ran at the speed of its single-buffered predecessor) -- slab and V planes are
+// single-buffered: two barriers per chunk, next slab fetched into registers under the MFMAs.  Restated by bxo_conv_wino_valid.
+template <int NE, int FOLD, int COUT, int D, int G, bool RELU>
+__global__ __launch_bounds__(CT, 2) void wino_pose_kernel(const float* __restrict__ in, const int32_t* __restrict__ units_dev, int max_units,
+                                                          const float* __restrict__ U, const float* __restrict__ bias, float* __restrict__ out,
+                                                          const int32_t* __restrict__ skip)
+{
+    if (skip && *skip) return;
+    constexpr int NT = COUT / 16, NCHUNK = NE / FOLD;
+    constexpr int TT = (D - 2) / 2, NTU = TT * TT, DO = D - 2, PIN = D * FOLD * D, POUT = DO * DO;
+    constexpr int ROWS = G * NTU, RT = (ROWS + 15) / 16, VR = RT * 16, VPL = VR * ROWF;
+    constexpr int SLABF = G * D * D * ROWF;
+    constexpr int NPIECE = G * D * D * 4, NLD = (NPIECE + CT - 1) / CT;
+    constexpr int NITEM = 4 * ROWS * 4, NIT = (NITEM + CT - 1) / CT;
+    static_assert(ROWS <= 64 && 2 * 2 * ROWS * CW <= 16 * VPL, "tile rows fit four MFMA row tiles; the r exchange fits the V planes");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* slab = reinterpret_cast<float*>(smem);
+    float* Vp = slab + SLABF;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave & 1, ctl = wave >> 1;
+    const int ctg = (int)blockIdx.y * (CW / 16) + ctl;
+    const int li = lane & 15, kk = lane >> 4;
+
+    int units = max_units;
+    if (units_dev) { const int ud = *units_dev; units = ud < max_units ? ud : max_units; }
+    const int ngroups = (units + G - 1) / G;
+    if ((int)blockIdx.x >= ngroups) return;
+
+    for (int i = tid; i < (SLABF + 16 * VPL) / 4; i += CT) reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const float4* in4 = reinterpret_cast<const float4*>(in);
+    float4 st[NLD];
+    auto gload = [&](int ug, int e) {
+        const int cc = e / FOLD, b = e - cc * FOLD;
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int f = tid + q * CT;
+            const int row = f >> 2, part = f & 3;
+            const int g = row / (D * D), p = row - g * (D * D);
+            const int n = p / D, l = p - n * D;
+            const int u = ug * G + g;
+            st[q] = (f < NPIECE && u < units) ? in4[(((size_t)u * NCHUNK + cc) * PIN + (n * FOLD + b) * D + l) * 4 + part]
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lwrite = [&]() {
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int f = tq + q * CT;
+            if (f < NPIECE) *reinterpret_cast<float4*>(slab + (f >> 2) * ROWF + (f & 3) * 4) = st[q];
+        }
+    };
+    int ia[NIT], ib[NIT], iv[NIT];
+    float isg[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int it = tid + k * CT;
+        ia[k] = -1; ib[k] = 0; iv[k] = 0; isg[k] = 0.f;
+        if (it < NITEM) {
+            const int x = it / (ROWS * 4), rem = it - x * (ROWS * 4);
+            const int R = rem >> 2, part = rem & 3;
+            const int g = R / NTU, t = R - g * NTU;
+            const int tr = t / TT, tc = t - tr * TT;
+            const int ra = x == 0 ? 0 : (x == 2 ? 2 : 1);
+            const int rb = x == 0 ? 2 : (x == 1 ? 2 : (x == 2 ? 1 : 3));
+            isg[k] = x == 1 ? 1.0f : -1.0f;
+            ia[k] = (g * D * D + (2 * tr + ra) * D + 2 * tc) * ROWF + part * 4;
+            ib[k] = (g * D * D + (2 * tr + rb) * D + 2 * tc) * ROWF + part * 4;
+            iv[k] = (x * 4) * VPL + R * ROWF + part * 4;
+        }
+    }
+    auto transform = [&]() {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            if (ia[k] < 0) continue;
+            const float sg = isg[k];
+            float4 tj[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 a = *reinterpret_cast<const float4*>(slab + ia[k] + j * ROWF);
+                const float4 b = *reinterpret_cast<const float4*>(slab + ib[k] + j * ROWF);
+                tj[j] = make_float4(fmaf(sg, b.x, a.x), fmaf(sg, b.y, a.y), fmaf(sg, b.z, a.z), fmaf(sg, b.w, a.w));
+            }
+            float* vd = Vp + iv[k];
+            *reinterpret_cast<float4*>(vd) = make_float4(tj[0].x - tj[2].x, tj[0].y - tj[2].y, tj[0].z - tj[2].z, tj[0].w - tj[2].w);
+            *reinterpret_cast<float4*>(vd + VPL) = make_float4(tj[1].x + tj[2].x, tj[1].y + tj[2].y, tj[1].z + tj[2].z, tj[1].w + tj[2].w);
+            *reinterpret_cast<float4*>(vd + 2 * VPL) = make_float4(tj[2].x - tj[1].x, tj[2].y - tj[1].y, tj[2].z - tj[1].z, tj[2].w - tj[1].w);
+            *reinterpret_cast<float4*>(vd + 3 * VPL) = make_float4(tj[1].x - tj[3].x, tj[1].y - tj[3].y, tj[1].z - tj[3].z, tj[1].w - tj[3].w);
+        }
+    };
+
+    const int col = ctg * 16 + li;
+    const float bv = bias[col];
+    const float4* wbase = reinterpret_cast<const float4*>(U) + ((size_t)(half * 8) * NT + ctg) * 64 + lane;
+    const char* abase = reinterpret_cast<const char*>(Vp) + ((half * 8 * VR + li) * ROWF + kk * 4) * 4;
+
+    f32x4 acc[8][RT];
+    // B fragments in a ring of four: plane p + 4 (of this chunk, or plane p - 4 of the next) is requested right after the MFMAs of
+    // plane p -- 4 RT x 4 MFMAs ahead, longer than an L2 round trip
+    float4 bring[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) bring[p] = wbase[((size_t)p * NT) * 64];      // effective chunk 0, planes 0..3
+
+    int ug = blockIdx.x;
+    gload(ug, 0);
+    __syncthreads();                 // zero fill complete
+    lwrite();
+
+    for (;;) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[p][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int ugn = ug + (int)gridDim.x;
+#pragma unroll 1
+        for (int e = 0; e < NE; ++e) {
+            __syncthreads();         // slab of chunk e in place; every wave is done with the V planes of the chunk before
+            transform();
+            __syncthreads();         // V complete; the slab is free
+            const bool more = e + 1 < NE || ugn < ngroups;
+            if (e + 1 < NE) gload(ug, e + 1);
+            else if (ugn < ngroups) gload(ugn, 0);
+            const int en = e + 1 == NE ? 0 : e + 1;
+            // 8 planes x RT row tiles, A operand two steps ahead in a ring of three (static indices: no register copies)
+            f32x4 ar[3];
+            ar[0] = *reinterpret_cast<const f32x4*>(abase);
+            ar[1] = *reinterpret_cast<const f32x4*>(abase + ((RT > 1 ? 16 : VR) * ROWF) * 4);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const float4 bq = bring[p & 3];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const int s0 = p * RT + rt, s2 = s0 + 2;
+                    if (s2 < 8 * RT) ar[s2 % 3] = *reinterpret_cast<const f32x4*>(abase + (((s2 / RT) * VR + (s2 % RT) * 16) * ROWF) * 4);
+                    const f32x4 a = ar[s0 % 3];
+                    acc[p][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc[p][rt], 0, 0, 0);
+                    acc[p][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc[p][rt], 0, 0, 0);
+                    acc[p][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc[p][rt], 0, 0, 0);
+                    acc[p][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc[p][rt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                bring[p & 3] = p < 4 ? wbase[((size_t)(e * 16 + p + 4) * NT) * 64] : wbase[((size_t)(en * 16 + p - 4) * NT) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) lwrite();
+        }
+        __syncthreads();             // every wave is done with the V planes: their bytes carry the r exchange now
+        // ---- output transform (as wino_kernel): rows r = 2 half, 2 half + 1 of every 4-row group are finished by this half
+        float* ex = Vp;
+        int kko = kk, lio = ctl * 16 + li;
+        asm volatile("" : "+v"(kko), "+v"(lio));
+        float fa[RT][2][2], fb[RT][2][2];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int R = rt * 16 + kko * 4 + r;
+                const bool mine = (r >> 1) == half;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float ra = j == 0 ? (acc[0][rt][r] + acc[1][rt][r]) + acc[2][rt][r] : (acc[1][rt][r] - acc[2][rt][r]) - acc[3][rt][r];
+                    const float rb = j == 0 ? (acc[4][rt][r] + acc[5][rt][r]) + acc[6][rt][r] : (acc[5][rt][r] - acc[6][rt][r]) - acc[7][rt][r];
+                    const float v0 = half == 0 ? ra + rb : ra;
+                    const float v1 = rb;
+                    if (mine) { fa[rt][r & 1][j] = v0; fb[rt][r & 1][j] = v1; }
+                    else if (R < ROWS) {
+                        ex[((0 * 2 + j) * ROWS + R) * CW + lio] = v0;
+                        ex[((1 * 2 + j) * ROWS + R) * CW + lio] = v1;
+                    }
+                }
+            }
+        __syncthreads();
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int rp = 0; rp < 2; ++rp) {
+                const int R = rt * 16 + kko * 4 + 2 * half + rp;
+                const int g = R / NTU, t = R - g * NTU;
+                const int u = ug * G + g;
+                if (R < ROWS && u < units) {
+                    const int tr = t / TT, tc = t - tr * TT;
+                    float* ou = out + ((size_t)u * NT + ctg) * POUT * 16 + (4 * (li & 3) + (li >> 2));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float x0 = ex[((0 * 2 + j) * ROWS + R) * CW + lio], x1 = ex[((1 * 2 + j) * ROWS + R) * CW + lio];
+                        const float s01 = half == 0 ? fa[rt][rp][j] : x0;
+                        const float r1 = half == 0 ? fb[rt][rp][j] : x1;
+                        const float r2 = half == 0 ? x0 : fa[rt][rp][j];
+                        const float r3 = half == 0 ? x1 : fb[rt][rp][j];
+                        float y0 = (s01 + r2) + bv;
+                        float y1 = ((r1 - r2) - r3) + bv;
+                        if (RELU) { y0 = y0 > 0.0f ? y0 : 0.0f; y1 = y1 > 0.0f ? y1 : 0.0f; }
+                        const int w = 2 * tc + j;
+                        ou[((2 * tr) * DO + w) * 16] = y0;
+                        ou[((2 * tr + 1) * DO + w) * 16] = y1;
+                    }
+                }
+            }
+        ug = ugn;
+        if (ug >= ngroups) break;
+    }
+}
+
+template <int NE, int FOLD, int COUT, int D, int G, bool RELU>
+int launch_wino_pose(bx_ctx* c, int layer, hipStream_t s, const ConvLayerDev& L, const float* in, const int32_t* units_dev, int max_units,
+                     float* out)
+{
+    constexpr int TT = (D - 2) / 2, ROWS = G * TT * TT, RT = (ROWS + 15) / 16;
+    constexpr size_t LDS = (size_t)(G * D * D * ROWF + 16 * RT * 16 * ROWF) * 4;
+    static_assert(LDS <= 160 * 1024, "slab + V planes fit the LDS");
+    if (L.nchunk * FOLD != NE || L.cout != COUT || (L.relu != 0) != RELU || !L.Wwino || L.ntaps != 9 * FOLD) {
+        bx_set_error("winograd CostNet layer %d: geometry mismatch (%d chunks, %d taps, %d channels)", layer, L.nchunk, L.ntaps, L.cout);
+        return BX_ERR_STATE;
+    }
+    auto k = wino_pose_kernel<NE, FOLD, COUT, D, G, RELU>;
+    int& cap = c->wino_pose_cap[layer];
+    if (cap == 0) {
+        BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        int occ = 0;
+        BX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, CT, LDS));
+        cap = (occ >= 1 ? occ : 1) * c->n_cu / (COUT / CW);
+        if (cap < 1) cap = 1;
+        if (c->conv_cap_override > 0 && c->conv_cap_override < cap) cap = c->conv_cap_override;
+    }
+    int grid = (max_units + G - 1) / G;
+    if (grid <= 0) return BX_OK;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(k, dim3(grid, COUT / CW), dim3(CT), LDS, s, in, units_dev, max_units, L.Wwino, L.b, out, c->skip);
+    BX_LAUNCH_CHECK();
+    return BX_OK;
+}
 }  // namespace
 
 // U = G g G^T of every (chunk, channel, output channel) in binary64, rounded once (the same expressions as the oracle's
 // wino_filter), packed as B fragments [chunk * 16 + plane][column tile][lane = kk*16 + li][4], element i = U[plane][chunk][kk + 4 i][col]
-int bxk_wino_weights(const float* w /* [nchunk][9][16][cout] */, int nchunk, int cout, float** d_out)
+int bxk_wino_weights(const float* w /* [nchunk][9 * fold][16][cout] */, int nchunk, int fold, int cout, float** d_out)
 {
-    const int nt = cout / 16;
-    std::vector<float> frag((size_t)nchunk * 16 * nt * 64 * 4, 0.0f);
-    for (int cc = 0; cc < nchunk; ++cc)
+    // fold = 3: the k(3,3,3) CostNet layer, tap = (a*3 + b)*3 + d, effective chunk e = chunk * 3 + b; fold = 1: tap = a*3 + d
+    const int nt = cout / 16, ntaps = 9 * fold;
+    std::vector<float> frag((size_t)nchunk * fold * 16 * nt * 64 * 4, 0.0f);
+    for (int cs = 0; cs < nchunk; ++cs)
+      for (int fb = 0; fb < fold; ++fb) {
+        const int cc = cs * fold + fb;                     // effective chunk
         for (int ch = 0; ch < 16; ++ch)
             for (int o = 0; o < cout; ++o) {
                 double g[3][3], Gg[4][3];
                 for (int kh = 0; kh < 3; ++kh)
-                    for (int kw = 0; kw < 3; ++kw) g[kh][kw] = (double)w[(((size_t)cc * 9 + kh * 3 + kw) * 16 + ch) * cout + o];
+                    for (int kw = 0; kw < 3; ++kw)
+                        g[kh][kw] = (double)w[(((size_t)cs * ntaps + (fold == 3 ? (kh * 3 + fb) * 3 + kw : kh * 3 + kw)) * 16 + ch) * cout + o];
                 for (int kw = 0; kw < 3; ++kw) {
                     Gg[0][kw] = g[0][kw];
                     Gg[1][kw] = 0.5 * ((g[0][kw] + g[1][kw]) + g[2][kw]);
@@ -322,6 +567,7 @@ int bxk_wino_weights(const float* w /* [nchunk][9][16][cout] */, int nchunk, int
                     }
                 }
             }
+      }
     BX_HIP(hipMalloc(reinterpret_cast<void**>(d_out), frag.size() * sizeof(float)));
     BX_HIP(hipMemcpy(*d_out, frag.data(), frag.size() * sizeof(float), hipMemcpyHostToDevice));
     return BX_OK;
@@ -340,6 +586,22 @@ int bxk_wino(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t
         case 4: return launch_wino<8, 64, true>(c, layer, s, L, in, max_units, out);
         case 5: return launch_wino<4, 64, true>(c, layer, s, L, in, max_units, out);
         // layers 6 and 7 (32 output channels: half a workgroup) stay on the direct kernels
+    }
+    return -1;
+}
+
+// CostNet layers 1..5 in the Winograd form; returns -1 for the other layers (caller falls back to the direct kernels)
+int bxk_wino_pose(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t* units_dev, int max_units, float* out)
+{
+    if (max_units < 1) return -1;
+    const ConvLayerDev& L = c->pose[layer];
+    switch (layer) {
+        //                             NE FOLD COUT  D  G
+        case 1: return launch_wino_pose<6, 3, 64, 18, 1, true>(c, layer, s, L, in, units_dev, max_units, out);
+        case 2: return launch_wino_pose<4, 1, 64, 16, 1, true>(c, layer, s, L, in, units_dev, max_units, out);
+        case 3: return launch_wino_pose<4, 1, 128, 14, 1, true>(c, layer, s, L, in, units_dev, max_units, out);
+        case 4: return launch_wino_pose<8, 1, 128, 12, 2, true>(c, layer, s, L, in, units_dev, max_units, out);
+        case 5: return launch_wino_pose<8, 1, 64, 10, 4, true>(c, layer, s, L, in, units_dev, max_units, out);
     }
     return -1;
 }

@@ -156,6 +156,31 @@ def conv_wino(x, W, bias, relu, ele_n=7, azi_n=20):
     return out
 
 
+def conv_wino_valid(x, W, bias, relu, D, fold):
+    """CostNet layer as a valid Winograd F(2x2, 3x3) convolution over a D x D map (bxo_conv_wino_valid); fold = 3 for the k(3,3,3)
+    layer (its three k rows become input channels), 1 for the k(3,1,3) layers.  x [units][n_chunks][D*fold*D][16]."""
+    x, W, bias = _f(x), _f(W), _f(bias)
+    units, n_chunks, p_in, _ = x.shape
+    cout = W.shape[-1]
+    assert p_in == D * fold * D and W.shape == (n_chunks, 9 * fold, 16, cout), (x.shape, W.shape, D, fold)
+    out = np.zeros((units, (cout + 15) // 16, (D - 2) * (D - 2), 16), np.float32)
+    lib().bxo_conv_wino_valid(_p(x), C.c_int(units), C.c_int(n_chunks), C.c_int(D), C.c_int(fold), _p(W), _p(bias), C.c_int(cout),
+                              C.c_int(int(relu)), _p(out))
+    return out
+
+
+# CostNet layers 1..5 (3 x 3 kernels over the two azimuth-like axes): "winograd" (default, k_wino.hip) | "direct" (conv_kernel);
+# follows the product's switch BX_POSE_CONV
+POSE_CONV = os.environ.get("BX_POSE_CONV", "winograd")
+
+
+def pose_conv(layer, x, tap, dims, W, bias, relu):
+    """CostNet layer `layer` (1..9) in the arithmetic the product is configured for; dims = input dims (n, k, l) of the layer."""
+    if POSE_CONV == "winograd" and 1 <= layer <= 5:
+        return conv_wino_valid(x, W, bias, relu, dims[0], dims[1])
+    return conv(x, tap, W, bias, relu)
+
+
 # which restatement of the Cylindrical_Net layers the chain and the tests use -- it follows the product's switch (BX_DESC_CONV,
 # read by bx_create): "winograd" (default) = bxo_conv_wino (k_wino.hip), "direct" = fmaf chain over chunk > tap > channel (conv_kernel, k_conv.hip)
 DESC_CONV = os.environ.get("BX_DESC_CONV", "winograd")

@@ -52,9 +52,10 @@ def pose_forward(s_equi, t_equi, s_mids, t_mids, pw, cfg, cap=None, tag=""):
         layers = layers[1:]
     else:
         x = O.cost_volume(s_equi, t_equi, s_mids, t_mids, cfg.patch.ele_n, cfg.patch.azi_n)
-    for L, (dims, k, out) in layers:
+    first = len(pw["pose"]) - len(layers)
+    for li, (L, (dims, k, out)) in enumerate(layers):
         tap, _ = W.valid_tap_table(dims, k)
-        x = O.conv(x, tap, L["W"], L["b"], L["relu"])
+        x = O.pose_conv(first + li, x, tap, dims, L["W"], L["b"], L["relu"])      # layers 1..5: Winograd or direct form (BX_POSE_CONV)
     ind = O.soft_argmax(x, cfg.patch.azi_n)
     if cap is not None:
         cap[tag + "logits"] = x

@@ -323,7 +323,7 @@ def test_conv_layers_group_walk(bx, packed, oracle, monkeypatch):
                 sel = np.sort(rng.choice(units, NSAMP, replace=False))
                 sel[-1] = units - 1
                 ts = torch.as_tensor(sel, device=x.device)
-                ref = oracle.conv(lib.chunked_to_logical(_np(x[ts])), tap, L["W"], L["b"], L["relu"])
+                ref = oracle.pose_conv(l, lib.chunked_to_logical(_np(x[ts])), tap, dims, L["W"], L["b"], L["relu"])
                 assert np.array_equal(lib.chunked_to_logical(_np(y[ts])), ref), ("pose", l)
                 x = y
         finally:

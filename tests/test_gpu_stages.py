@@ -233,7 +233,7 @@ def test_pose_conv_layer_exact(ctx, oracle, bx, packed, layer):
     rng = np.random.default_rng(100 + layer)
     units = 37 if layer >= 5 else 5
     x = rng.standard_normal((units, nch, int(np.prod(dims)), 16)).astype(np.float32)
-    ref = oracle.conv(x, tap, L["W"], L["b"], L["relu"])
+    ref = oracle.pose_conv(layer, x, tap, dims, L["W"], L["b"], L["relu"])      # layers 1..5: Winograd or direct form (BX_POSE_CONV)
     out = ctx.conv_layer(1, layer, lib.logical_to_chunked(x), ref.shape)
     assert np.array_equal(lib.chunked_to_logical(_np(out)), ref)
 
@@ -292,9 +292,10 @@ def test_pose_net(oracle, bx, packed, form, monkeypatch):
         layers = layers[1:]
     else:
         x = oracle.cost_volume(se, te, sm, tm)
-    for L, (dims, k, _) in layers:
+    first = 10 - len(layers)
+    for li, (L, (dims, k, _)) in enumerate(layers):
         tap, _ = bx.weights.valid_tap_table(dims, k)
-        x = oracle.conv(x, tap, L["W"], L["b"], L["relu"])
+        x = oracle.pose_conv(first + li, x, tap, dims, L["W"], L["b"], L["relu"])
     rind = oracle.soft_argmax(x)
     smp = np.zeros(K, np.int32); smp[:m] = sm
     tmp = np.zeros(K, np.int32); tmp[:m] = tm
