@@ -362,17 +362,27 @@ def main():
         roof_cn = None
         if pose_n:
             pose_n = max(1, int(round(pose_n * ran)))
-            direct = os.environ.get("BX_COST_L0") == "direct"
-            mmac = COSTNET_MMAC_PER_MATCH if direct else COSTNET_MMAC_PER_MATCH - COSTNET_L0_MMAC      # MFMA work that is executed
-            fl = 2.0 * mmac * 1e6 * mean_m
+            direct0 = os.environ.get("BX_COST_L0") == "direct"
+            wino_p = os.environ.get("BX_POSE_CONV", "winograd") != "direct"
+            # algorithmic work of layers 1..9 as the reference's convolutions run them (53.12 MMAC per match) + layer 0: 26.87 MMAC on the
+            # materialised cost volume, or the 1.42 MMAC that remain of it after the algebraic collapse (k_cost.hip)
+            alg = COSTNET_MMAC_PER_MATCH if direct0 else COSTNET_MMAC_PER_MATCH - COSTNET_L0_MMAC + COSTNET_L0_COLLAPSED_MMAC
+            # issued on the f32 matrix pipe: layers 1..5 as Winograd F(2x2,3x3) (16 planes x padded tile rows), layers 6..9 direct;
+            # the collapsed layer 0 is binary64 VALU work
+            ex = (27.263 + 1.661 if wino_p else 53.124) + (COSTNET_L0_MMAC if direct0 else 0.0)
+            fl = 2.0 * alg * 1e6 * mean_m
             ach = fl / (pose_ms / pose_n * 1e-3) / 1e12
-            roof_cn = {"kernel": ("cost_l1_kernel" if direct else "cost_l0_kernel (collapsed layer 0, binary64 VALU)") + " + conv_kernel x9 + soft_argmax (CostNet)",
+            ex_ach = 2.0 * ex * 1e6 * mean_m / (pose_ms / pose_n * 1e-3) / 1e12
+            roof_cn = {"kernel": ("cost_l1_kernel" if direct0 else "cost_l0_kernel (collapsed layer 0, binary64 VALU)") +
+                                 (" + wino_pose_kernel x5 (Winograd F(2x2,3x3)) + conv_kernel x4" if wino_p else " + conv_kernel x9") + " + soft_argmax (CostNet)",
                        "bound": "mfma", "achieved": round(ach, 3),
                        "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MATRIX_TFLOPS, 4),
-                       "flops_note": "executed f32 MFMA flops (layers 1..9: %.1f MMAC per match%s) over the time of the WHOLE CostNet incl. layer 0; "
-                                     "reference-equivalent work = 80.0 MMAC per match -> %.1f TFLOP/s equivalent"
-                                     % (mmac, "" if direct else "; layer 0 costs 1.42 MMAC of binary64 fma instead of 26.9 MMAC",
-                                        2.0 * COSTNET_MMAC_PER_MATCH * 1e6 * mean_m / (pose_ms / pose_n * 1e-3) / 1e12),
+                       "flops_note": "ALGORITHMIC flops (%.2f MMAC per match: layers 1..9 as direct convolutions + layer 0 %s) over the time of the "
+                                     "whole CostNet; the reference's own arithmetic (80.0 MMAC per match on the materialised cost volume) in the same "
+                                     "time = %.1f TFLOP/s; executed_* = flops issued on the f32 matrix pipe (%.2f MMAC per match)"
+                                     % (alg, "on the materialised volume" if direct0 else "after its algebraic collapse: 1.42 MMAC",
+                                        2.0 * COSTNET_MMAC_PER_MATCH * 1e6 * mean_m / (pose_ms / pose_n * 1e-3) / 1e12, ex),
+                       "executed_achieved": round(ex_ach, 3), "executed_frac": round(ex_ach / PEAK_F32_MATRIX_TFLOPS, 4),
                        "traffic": None, "mfma_busy": busy_cn.get("costnet") if fresh(busy_cn) else None,
                        "avg_launch_ms": round(pose_ms / pose_n, 4), "launches": pose_n,
                        "algorithmic_flops_per_launch": fl, "mean_matches_per_launch": round(mean_m, 1)}
