@@ -38,7 +38,63 @@ constexpr int VPLANE = VROWS * ROWF;             // floats per (xi, nu) plane
 constexpr size_t WINO_LDS = (size_t)(2 * SLAB_FLOATS + 2 * 16 * VPLANE) * 4;   // 2 x 17.6 KB + 2 x 61.4 KB = 158 KB
 constexpr int CW = 64, CT = 512;                 // output channels / threads of a workgroup
 static_assert(WINO_LDS <= 160 * 1024, "double-buffered slab + V planes fit the LDS");
-static_assert(2 * 2 * NT_ * CW <= 16 * VPLANE, "the r exchange fits the bytes of one set of V planes");
+static_assert(4 * NT_ * CW <= 16 * VPLANE, "E of one output column fits the bytes of one set of V planes");
+
+// Output transform shared by the kernels below.  Lane (li, kk) of wave (ct, half) holds M[xi][0..3] (xi = 2 half, 2 half + 1) of tile
+// rows R = rt*16 + 4 kk + r for ONE output channel; r_xi[j] = (M0 + M1) + M2 | (M1 - M2) - M3 is lane-local.  Per output column j
+// every wave writes its two quantities -- half 0: r0 + r1 and r1, half 1: r2 and r3 -- of all its tile rows to LDS as
+// E[quantity][R][64 channels of the workgroup in OUTPUT slot order], 16-channel groups XOR-swizzled by kk = (R >> 2) & 3 (the four
+// kk of a wave hit four different bank groups: conflict-free b32 writes, and a row stays 64 contiguous floats for b128 reads);
+// then ALL threads walk (R, 4-channel quad) in output order: four ds_read_b128, Y[0][j] = ((r0 + r1) + r2) + bias,
+// Y[1][j] = ((r1 - r2) - r3) + bias, ReLU, two 16-byte stores (a lane-local finish would store 4 bytes per lane: six times the
+// store instructions).  E of one j = 4 x ROWS x 64 floats lives in the bytes of a consumed set of V planes.
+template <int RT, int ROWS, bool RELU, class StoreFn>
+__device__ __forceinline__ void wino_output(const f32x4 (&acc)[8][RT], float* ex, int half, int ctl, int li, int kk, int tid,
+                                            const float4 b4, StoreFn&& store)
+{
+    int kko = kk, slot = ctl * 16 + 4 * (li & 3) + (li >> 2), tq = tid;
+    asm volatile("" : "+v"(kko), "+v"(slot), "+v"(tq));   // keeps the LDS / store addresses out of loop-invariant hoisting
+    const int wcol = slot ^ (kko << 4);
+    constexpr int NITEM = ROWS * 16, NIT = (NITEM + CT - 1) / CT;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int R = rt * 16 + kko * 4 + r;
+                const float ra = j == 0 ? (acc[0][rt][r] + acc[1][rt][r]) + acc[2][rt][r] : (acc[1][rt][r] - acc[2][rt][r]) - acc[3][rt][r];
+                const float rb = j == 0 ? (acc[4][rt][r] + acc[5][rt][r]) + acc[6][rt][r] : (acc[5][rt][r] - acc[6][rt][r]) - acc[7][rt][r];
+                const float q0 = half == 0 ? ra + rb : ra;          // half 0: r0 + r1 | half 1: r2
+                if (rt * 16 + 15 < ROWS || R < ROWS) {
+                    ex[((half * 2 + 0) * ROWS + R) * 64 + wcol] = q0;
+                    ex[((half * 2 + 1) * ROWS + R) * 64 + wcol] = rb;   // half 0: r1 | half 1: r3
+                }
+            }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int it = tq + k * CT;
+            if (it < NITEM) {
+                const int R = it >> 4, quad = it & 15;
+                const float* e = ex + R * 64 + ((quad * 4) ^ (((R >> 2) & 3) << 4));
+                const float4 s01 = *reinterpret_cast<const float4*>(e);
+                const float4 r1 = *reinterpret_cast<const float4*>(e + ROWS * 64);
+                const float4 r2 = *reinterpret_cast<const float4*>(e + 2 * ROWS * 64);
+                const float4 r3 = *reinterpret_cast<const float4*>(e + 3 * ROWS * 64);
+                float4 y0 = make_float4((s01.x + r2.x) + b4.x, (s01.y + r2.y) + b4.y, (s01.z + r2.z) + b4.z, (s01.w + r2.w) + b4.w);
+                float4 y1 = make_float4(((r1.x - r2.x) - r3.x) + b4.x, ((r1.y - r2.y) - r3.y) + b4.y, ((r1.z - r2.z) - r3.z) + b4.z,
+                                        ((r1.w - r2.w) - r3.w) + b4.w);
+                if (RELU) {
+                    y0 = make_float4(y0.x > 0.f ? y0.x : 0.f, y0.y > 0.f ? y0.y : 0.f, y0.z > 0.f ? y0.z : 0.f, y0.w > 0.f ? y0.w : 0.f);
+                    y1 = make_float4(y1.x > 0.f ? y1.x : 0.f, y1.y > 0.f ? y1.y : 0.f, y1.z > 0.f ? y1.z : 0.f, y1.w > 0.f ? y1.w : 0.f);
+                }
+                store(R, j, quad, y0, y1);
+            }
+        }
+        __syncthreads();             // E(j) consumed: the next j (or the next transform) may overwrite it
+    }
+}
 
 template <int NCHUNK, int COUT, bool RELU>
 __global__ __launch_bounds__(CT, 2) void wino_kernel(const float* __restrict__ in, int units, const float* __restrict__ U,
@@ -137,8 +193,10 @@ __global__ __launch_bounds__(CT, 2) void wino_kernel(const float* __restrict__ i
         }
     };
 
-    const int col = ctg * 16 + li;
-    const float bv = bias[col];
+    // bias of the four output slots 4 a .. 4 a + 3 (a = quad & 3) of column tile quad >> 2 this thread stores: slot s holds channel
+    // (s & 3) * 4 + (s >> 2) of the tile
+    const float* bq = bias + ((int)blockIdx.y * (CW / 16) + ((tid & 15) >> 2)) * 16 + (tid & 3);
+    const float4 b4 = make_float4(bq[0], bq[4], bq[8], bq[12]);
     // B fragments: [chunk * 16 + plane][column tile][lane][4] (the layout of the direct kernels with 16 "taps"); this wave's planes
     // are half * 8 + 0..7
     const float4* wbase = reinterpret_cast<const float4*>(U) + ((size_t)(half * 8) * NT + ctg) * 64 + lane;
@@ -205,64 +263,18 @@ __global__ __launch_bounds__(CT, 2) void wino_kernel(const float* __restrict__ i
         if (mfma_first && g + 1 < NG) transform(g + 1);
         __syncthreads();             // V(g + 1) and the slab of chunk g + 2 complete; plane set g & 1 is free
         if (cc != NCHUNK - 1) continue;
-        // ---- output transform of the unit.  Lane (li, kk) of wave (ct, half) holds M[xi][0..3] (xi = 2 half, 2 half + 1) of tiles
-        //      rt*16 + 4 kk + r and channel `col`: r_xi[0] = (M0 + M1) + M2, r_xi[1] = (M1 - M2) - M3.  half 0 hands r0 + r1 and r1 to
-        //      half 1 through LDS [which][j][tile][CW] (the bytes of plane set g & 1, untouched by the next transform until the barriers)
+        // ---- output transform of the unit (wino_output above); E lives in the bytes of plane set g & 1, untouched by the next
+        //      transform until the helper's last barrier (the padding rows 40..47 of some planes then hold E data: they feed
+        //      accumulator rows that are never stored)
         const int u = unit_of(g);
-        float* ex = V0 + (g & 1) * 16 * VPLANE;
-        int kko = kk, lio = ctl * 16 + li;
-        asm volatile("" : "+v"(kko), "+v"(lio));   // keeps the exchange / store addresses out of loop-invariant hoisting
-        // both halves fold their two rows; rows r = 2, 3 of every row tile are finished by half 1, rows r = 0, 1 by half 0: each half
-        // hands the other what it needs for the other's rows -- half 0: (r0 + r1, r1), half 1: (r2, r3) -- and stores its own
-        float fa[3][2][2], fb[3][2][2];            // [rt][r within the own pair][j]: half 0: (r0 + r1, r1); half 1: (r2, r3)
-#pragma unroll
-        for (int rt = 0; rt < 3; ++rt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int t = rt * 16 + kko * 4 + r;
-                const bool mine = (r >> 1) == half;                 // this half stores rows r = 2 half, 2 half + 1
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float ra = j == 0 ? (acc[0][rt][r] + acc[1][rt][r]) + acc[2][rt][r] : (acc[1][rt][r] - acc[2][rt][r]) - acc[3][rt][r];
-                    const float rb = j == 0 ? (acc[4][rt][r] + acc[5][rt][r]) + acc[6][rt][r] : (acc[5][rt][r] - acc[6][rt][r]) - acc[7][rt][r];
-                    const float v0 = half == 0 ? ra + rb : ra;      // half 0: r0 + r1 | half 1: r2
-                    const float v1 = rb;                            // half 0: r1      | half 1: r3
-                    if (mine) { fa[rt][r & 1][j] = v0; fb[rt][r & 1][j] = v1; }
-                    else if (t < NT_) {
-                        ex[((0 * 2 + j) * NT_ + t) * CW + lio] = v0;
-                        ex[((1 * 2 + j) * NT_ + t) * CW + lio] = v1;
-                    }
-                }
-            }
-        __syncthreads();
-        {
-            float* ou = out + ((size_t)u * NT + ctg) * BX_EA * 16 + (4 * (li & 3) + (li >> 2));
-#pragma unroll
-            for (int rt = 0; rt < 3; ++rt)
-#pragma unroll
-                for (int rp = 0; rp < 2; ++rp) {
-                    const int t = rt * 16 + kko * 4 + 2 * half + rp;
-                    if (t < NT_) {
-                        const int tr = t / TC, tc = t - tr * TC;
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const float x0 = ex[((0 * 2 + j) * NT_ + t) * CW + lio], x1 = ex[((1 * 2 + j) * NT_ + t) * CW + lio];
-                            const float s01 = half == 0 ? fa[rt][rp][j] : x0;      // r0 + r1
-                            const float r1 = half == 0 ? fb[rt][rp][j] : x1;
-                            const float r2 = half == 0 ? x0 : fa[rt][rp][j];
-                            const float r3 = half == 0 ? x1 : fb[rt][rp][j];
-                            float y0 = (s01 + r2) + bv;
-                            float y1 = ((r1 - r2) - r3) + bv;
-                            if (RELU) { y0 = y0 > 0.0f ? y0 : 0.0f; y1 = y1 > 0.0f ? y1 : 0.0f; }
-                            const int w = 2 * tc + j;
-                            ou[((2 * tr) * BX_AZI + w) * 16] = y0;
-                            if (2 * tr + 1 < BX_ELE) ou[((2 * tr + 1) * BX_AZI + w) * 16] = y1;
-                        }
-                    }
-                }
-        }
-        __syncthreads();             // the exchange bytes become V planes again (their padding rows may hold exchange data now:
-                                     // rows 40..47 feed accumulator rows that are never stored)
+        wino_output<3, NT_, RELU>(acc, V0 + (g & 1) * 16 * VPLANE, half, ctl, li, kk, tid, b4,
+                                  [&](int R, int j, int quad, const float4& y0, const float4& y1) {
+                                      const int tr = R / TC, tc = R - tr * TC;
+                                      float* ou = out + ((((size_t)u * NT + (int)blockIdx.y * (CW / 16) + (quad >> 2)) * BX_EA +
+                                                          (2 * tr) * BX_AZI + 2 * tc + j) * 16 + (quad & 3) * 4);
+                                      *reinterpret_cast<float4*>(ou) = y0;
+                                      if (2 * tr + 1 < BX_ELE) *reinterpret_cast<float4*>(ou + BX_AZI * 16) = y1;
+                                  });
     }
 }
 
@@ -311,7 +323,7 @@ __global__ __launch_bounds__(CT, 2) void wino_pose_kernel(const float* __restric
     constexpr int SLABF = G * D * D * ROWF;
     constexpr int NPIECE = G * D * D * 4, NLD = (NPIECE + CT - 1) / CT;
     constexpr int NITEM = 4 * ROWS * 4, NIT = (NITEM + CT - 1) / CT;
-    static_assert(ROWS <= 64 && 2 * 2 * ROWS * CW <= 16 * VPL, "tile rows fit four MFMA row tiles; the r exchange fits the V planes");
+    static_assert(ROWS <= 64 && 4 * ROWS * CW <= 16 * VPL, "tile rows fit four MFMA row tiles; E of one output column fits the V planes");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* slab = reinterpret_cast<float*>(smem);
     float* Vp = slab + SLABF;
@@ -391,8 +403,8 @@ __global__ __launch_bounds__(CT, 2) void wino_pose_kernel(const float* __restric
         }
     };
 
-    const int col = ctg * 16 + li;
-    const float bv = bias[col];
+    const float* bq = bias + ((int)blockIdx.y * (CW / 16) + ((tid & 15) >> 2)) * 16 + (tid & 3);
+    const float4 b4 = make_float4(bq[0], bq[4], bq[8], bq[12]);
     const float4* wbase = reinterpret_cast<const float4*>(U) + ((size_t)(half * 8) * NT + ctg) * 64 + lane;
     const char* abase = reinterpret_cast<const char*>(Vp) + ((half * 8 * VR + li) * ROWF + kk * 4) * 4;
 
@@ -446,58 +458,19 @@ __global__ __launch_bounds__(CT, 2) void wino_pose_kernel(const float* __restric
             }
             if (more) lwrite();
         }
-        __syncthreads();             // every wave is done with the V planes: their bytes carry the r exchange now
-        // ---- output transform (as wino_kernel): rows r = 2 half, 2 half + 1 of every 4-row group are finished by this half
-        float* ex = Vp;
-        int kko = kk, lio = ctl * 16 + li;
-        asm volatile("" : "+v"(kko), "+v"(lio));
-        float fa[RT][2][2], fb[RT][2][2];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int R = rt * 16 + kko * 4 + r;
-                const bool mine = (r >> 1) == half;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float ra = j == 0 ? (acc[0][rt][r] + acc[1][rt][r]) + acc[2][rt][r] : (acc[1][rt][r] - acc[2][rt][r]) - acc[3][rt][r];
-                    const float rb = j == 0 ? (acc[4][rt][r] + acc[5][rt][r]) + acc[6][rt][r] : (acc[5][rt][r] - acc[6][rt][r]) - acc[7][rt][r];
-                    const float v0 = half == 0 ? ra + rb : ra;
-                    const float v1 = rb;
-                    if (mine) { fa[rt][r & 1][j] = v0; fb[rt][r & 1][j] = v1; }
-                    else if (R < ROWS) {
-                        ex[((0 * 2 + j) * ROWS + R) * CW + lio] = v0;
-                        ex[((1 * 2 + j) * ROWS + R) * CW + lio] = v1;
-                    }
-                }
-            }
-        __syncthreads();
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int rp = 0; rp < 2; ++rp) {
-                const int R = rt * 16 + kko * 4 + 2 * half + rp;
-                const int g = R / NTU, t = R - g * NTU;
-                const int u = ug * G + g;
-                if (R < ROWS && u < units) {
-                    const int tr = t / TT, tc = t - tr * TT;
-                    float* ou = out + ((size_t)u * NT + ctg) * POUT * 16 + (4 * (li & 3) + (li >> 2));
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const float x0 = ex[((0 * 2 + j) * ROWS + R) * CW + lio], x1 = ex[((1 * 2 + j) * ROWS + R) * CW + lio];
-                        const float s01 = half == 0 ? fa[rt][rp][j] : x0;
-                        const float r1 = half == 0 ? fb[rt][rp][j] : x1;
-                        const float r2 = half == 0 ? x0 : fa[rt][rp][j];
-                        const float r3 = half == 0 ? x1 : fb[rt][rp][j];
-                        float y0 = (s01 + r2) + bv;
-                        float y1 = ((r1 - r2) - r3) + bv;
-                        if (RELU) { y0 = y0 > 0.0f ? y0 : 0.0f; y1 = y1 > 0.0f ? y1 : 0.0f; }
-                        const int w = 2 * tc + j;
-                        ou[((2 * tr) * DO + w) * 16] = y0;
-                        ou[((2 * tr + 1) * DO + w) * 16] = y1;
-                    }
-                }
-            }
+        __syncthreads();             // every wave is done with the V planes: their bytes carry E now
+        wino_output<RT, ROWS, RELU>(acc, Vp, half, ctl, li, kk, tid, b4,
+                                    [&](int R, int j, int quad, const float4& y0, const float4& y1) {
+                                        const int g = R / NTU, t = R - g * NTU;
+                                        const int u = ug * G + g;
+                                        if (u < units) {
+                                            const int tr = t / TT, tc = t - tr * TT;
+                                            float* ou = out + ((((size_t)u * NT + (int)blockIdx.y * (CW / 16) + (quad >> 2)) * POUT +
+                                                                (2 * tr) * DO + 2 * tc + j) * 16 + (quad & 3) * 4);
+                                            *reinterpret_cast<float4*>(ou) = y0;
+                                            *reinterpret_cast<float4*>(ou + DO * 16) = y1;
+                                        }
+                                    });
         ug = ugn;
         if (ug >= ngroups) break;
     }
