@@ -1,10 +1,9 @@
 #!/bin/bash
-# round 3, call K: Winograd output transform in output order (swizzled LDS exchange, 16-byte stores) -- parity + per-kernel time
+# round 3, call K: quick parity + rate + per-kernel time of the Winograd kernels
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/r3k; rm -rf $OUT; mkdir -p $OUT
-timeout 600 python -m pytest tests/test_gpu_stages.py -x -q -k "desc_conv_layer_exact or desc_net or pose" 2>&1 | tail -4
-timeout 900 python -m pytest tests/test_gpu_headline.py tests/test_gpu_pipeline.py -x -q -k "descriptor_chain or matching_chain or vs_reference or golden" 2>&1 | tail -4
+timeout 600 python -m pytest tests/test_gpu_stages.py -x -q -k "desc_conv_layer_exact or desc_net or pose" 2>&1 | tail -3
 CMD="python bench.py --steps 24 --warmup 8 --no-cpu-baseline --latency-tiles 0 --e2e-pairs 0"
 run() { tag=$1; shift; env "$@" $CMD > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err; python - $OUT/bench_$tag.json $tag <<'PY'
 import json, sys
@@ -23,7 +22,7 @@ import glob, sqlite3
 for f in sorted(glob.glob("gpurun_out/r3k/kt/**/*.db", recursive=True)):
     db = sqlite3.connect(f)
     for name, calls, tot, avg, pct in db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
-        if "wino" in name:
+        if "wino" in name or "conv" in name or "cost" in name:
             n = name.replace("(anonymous namespace)::", "").replace("void ", "")
             print("%-60s %5d %10.1f us" % (n[:n.find("(")], calls, avg / 1e3 if avg > 1e5 else avg))
 PY
