@@ -451,9 +451,36 @@ def main():
                 out["e2e_pairs_per_s"] = e2e_rate(bx, pw, cfg, args, local, value)
             except Exception as e:      # the end-to-end leg must never take the benchmark line down
                 out["e2e_pairs_per_s"] = {"error": repr(e)}
+        sp = split_precision_note()
+        if sp:
+            out["experiments"] = {"split_precision": sp}
+            if sp["active_in_this_run"]:       # a line under the experiment's switch is not a line of the product
+                out["dtype"] = "f32 + bf16x3 split-precision layer (EXPERIMENT, not the shipped arithmetic)"
+                out["config"]["experiment"] = "BX_EXP_SPLIT_CONV=1"
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def split_precision_note():
+    """Pointer to the MEASUREMENT of a split-precision convolution (profiles/r03_split_precision.json; never part of `value`, `dtype`
+    or the roofline objects: the shipped path is exact f32).  None when the environment switch of the experiment is set -- a line
+    produced under BX_EXP_SPLIT_CONV=1 is not a benchmark line of the product and says so in config."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_split_precision.json")) as f:
+            d = json.load(f)
+        e = d["layer_error_vs_binary64"]
+        return {"file": "profiles/r03_split_precision.json", "shipped": False,
+                "what": "Cylindrical_Net layer 3 (128 -> 128) with 3 x bf16 pieces per fp32 operand, 6 partial products, fp32 accumulation "
+                        "(v_mfma_f32_16x16x32_bf16), measured against the exact f32 kernels; BX_EXP_SPLIT_CONV=1",
+                "max_abs_error_vs_binary64": {k: e[k]["max_abs"] for k in ("direct_f32", "winograd_f32", "split_bf16x3")},
+                "descriptor_max_abs_delta": d["descriptor_delta_vs_shipped"]["desc_max_abs_delta"],
+                "fixtures_counts_identical_to_reference": all(r["counts_split"] == r["counts_reference"] for r in d["reference_minted_fixtures"]),
+                "fixtures_max_pose_delta_vs_exact_deg_m": [max(r["pose_vs_exact_deg_m"][i] for r in d["reference_minted_fixtures"]) for i in (0, 1)],
+                "kernel_us_per_launch": d["kernel_time_us_per_launch_K5000"],
+                "active_in_this_run": bool(int(os.environ.get("BX_EXP_SPLIT_CONV", "0") or 0))}
+    except Exception:
+        return None
 
 
 def e2e_rate(bx, pw, cfg, args, device, hot_value):

@@ -558,6 +558,10 @@ int launch_conv(bx_ctx* c, int net, int layer, hipStream_t s, const ConvLayerDev
 int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, const int32_t* units_dev, int max_units, float* out)
 {
     constexpr int CYL = (BX_ELE + 2) * (BX_AZI + 2);   // 198 LDS rows per unit: cylindrical map + halo
+    if (net == 0 && c->exp_split) {
+        const int rcs = bxk_split_conv(c, s, layer, in, units_dev, max_units, out);   // measurement only (k_split.hip)
+        if (rcs >= 0) return rcs;
+    }
     if (net == 0 && c->use_wino) {
         const int rcw = bxk_wino(c, s, layer, in, units_dev, max_units, out);
         if (rcw >= 0) return rcw;
