@@ -18,9 +18,11 @@
 // one order, the other in the other -- the input transform of chunk g + 1 (thread item = (xi, tile, 4-channel quad): four V planes)
 // and the MFMAs of chunk g (one ds_read_b128 feeds four MFMAs; the B fragment of a plane, one 16-byte load per lane requested a
 // whole chunk ahead, is reused by the three row tiles): while one wave streams MFMAs the other does the transform's VALU / LDS work.
-// Output transform: every wave folds its two rows into r_xi[j] = (M0 + M1) + M2 | (M1 - M2) - M3 lane-locally; the two halves swap
-// what the other needs for ITS half of the tile rows through LDS (bytes of the consumed plane set) -- half 0: r0 + r1 and r1,
-// half 1: r2 and r3 -- and each forms Y[0][j] = ((r0 + r1) + r2), Y[1][j] = ((r1 - r2) - r3), adds the bias, applies ReLU and stores.
+// Output transform (wino_output): every wave folds its two rows into r_xi[j] = (M0 + M1) + M2 | (M1 - M2) - M3 lane-locally and hands
+// its two quantities -- half 0: r0 + r1 and r1, half 1: r2 and r3 -- to an LDS exchange (bytes of the consumed plane set) that all
+// threads then read in output order: Y[0][j] = ((r0 + r1) + r2), Y[1][j] = ((r1 - r2) - r3), + bias, ReLU, 16-byte stores.
+// Measured and not kept: two units per workgroup, one fat wave per SIMD, the slab write moved behind the
+// transform (3-5 % slower), -fno-slp-vectorize (no change).
 // MFMA work per unit and layer: 16 planes x 3 row tiles against 9 taps x 8.75 row tiles of the direct form (0.61x).
 #include "bx_common.h"
 #include <cstdlib>
