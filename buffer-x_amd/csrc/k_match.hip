@@ -73,11 +73,16 @@ __global__ __launch_bounds__(64) void desc_head_kernel(const float* __restrict__
 
 // ------------------------------------------------------------------ brute-force 1-NN on 32-D descriptors
 constexpr int NN_TILE = 64;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// One thread per query, the references of a tile in LDS, TWO references per step as packed fp32 (v_pk_add_f32 / v_pk_fma_f32: the
+// squared distance of a (query, reference) pair is still the fmaf chain over d = 0..31 from 0 -- the two chains of a step are the two
+// halves of one packed register, the query component is broadcast to both).  LDS layout [reference pair][d][2]: a ds_read_b128
+// delivers two components of both references.  Half the VALU instructions of the scalar form (round 3: 109 -> see DESIGN.md).
 __global__ __launch_bounds__(256) void nn1_kernel(const float* __restrict__ qd, int nq, const float* __restrict__ rd, int nr,
                                                   int seg_len, unsigned long long* __restrict__ keys, const int32_t* __restrict__ skip)
 {
     if (skip && *skip) return;
-    __shared__ float sr[NN_TILE][32];
+    __shared__ __attribute__((aligned(16))) float sr[NN_TILE / 2][32][2];
     const int i = blockIdx.x * 256 + threadIdx.x;
     float q[32];
     if (i < nq) {
@@ -93,20 +98,30 @@ __global__ __launch_bounds__(256) void nn1_kernel(const float* __restrict__ qd, 
     for (int t0 = j0; t0 < j1; t0 += NN_TILE) {
         __syncthreads();
         for (int f = threadIdx.x; f < NN_TILE * 32; f += 256) {
-            int jj = t0 + (f >> 5);
-            sr[f >> 5][f & 31] = jj < j1 ? rd[(size_t)jj * 32 + (f & 31)] : 0.f;
+            const int jl = f >> 5, jj = t0 + jl;
+            sr[jl >> 1][f & 31][jl & 1] = jj < j1 ? rd[(size_t)jj * 32 + (f & 31)] : 0.f;
         }
         __syncthreads();
         const int tn = min(NN_TILE, j1 - t0);
-        for (int jj = 0; jj < tn; ++jj) {
-            float acc = 0.0f;
+        for (int jp = 0; jp < (tn + 1) / 2; ++jp) {
+            f32x2 acc = {0.0f, 0.0f};
+            const float4* r4 = reinterpret_cast<const float4*>(&sr[jp][0][0]);
 #pragma unroll
-            for (int d = 0; d < 32; ++d) {
-                float df = q[d] - sr[jj][d];
-                acc = fmaf(df, df, acc);
+            for (int d2 = 0; d2 < 16; ++d2) {
+                const float4 t = r4[d2];                       // components 2 d2, 2 d2 + 1 of references 2 jp, 2 jp + 1
+                const f32x2 qa = {q[2 * d2], q[2 * d2]}, qb = {q[2 * d2 + 1], q[2 * d2 + 1]};
+                const f32x2 ra = {t.x, t.y}, rb = {t.z, t.w};
+                const f32x2 da = qa - ra;
+                acc = __builtin_elementwise_fma(da, da, acc);
+                const f32x2 db = qb - rb;
+                acc = __builtin_elementwise_fma(db, db, acc);
             }
-            unsigned long long key = ((unsigned long long)__float_as_uint(acc) << 32) | (unsigned)(t0 + jj);
-            best = key < best ? key : best;
+            const unsigned long long k0 = ((unsigned long long)__float_as_uint(acc.x) << 32) | (unsigned)(t0 + 2 * jp);
+            best = k0 < best ? k0 : best;
+            if (2 * jp + 1 < tn) {
+                const unsigned long long k1 = ((unsigned long long)__float_as_uint(acc.y) << 32) | (unsigned)(t0 + 2 * jp + 1);
+                best = k1 < best ? k1 : best;
+            }
         }
     }
     if (i < nq && j0 < j1) atomicMin(&keys[i], best);
@@ -386,7 +401,10 @@ int bxk_mutual(bx_ctx* c, hipStream_t s, const float* sd, int ns, const float* t
     }
     BX_HIP(hipMemsetAsync(c->nn_key[0], 0xff, sizeof(unsigned long long) * (size_t)ns, s));
     BX_HIP(hipMemsetAsync(c->nn_key[1], 0xff, sizeof(unsigned long long) * (size_t)nt, s));
-    const int SEG = 16;
+    // reference segments of 128 rows (two LDS tiles): 5000 queries x 16 segments were 1.2 waves per SIMD -- a latency-bound kernel at
+    // 111 us per launch; x 40 segments: 58 us (the packed atomicMin keys make the result independent of the segmentation)
+    const int nmax = nt > ns ? nt : ns;
+    const int SEG = nmax > 16 * 128 ? (nmax + 127) / 128 : 16;
     {
         int seg_len = (nt + SEG - 1) / SEG;
         seg_len = ((seg_len + NN_TILE - 1) / NN_TILE) * NN_TILE;
@@ -431,9 +449,9 @@ int bxk_consensus(bx_ctx* c, hipStream_t s, const float* R, const float* t, cons
         return BX_OK;
     }
     BX_HIP(hipMemsetAsync(c->cons_cnt, 0, sizeof(int32_t) * (size_t)max_M, s));
-    const int SEG = 16;
-    int seg_len = (max_M + SEG - 1) / SEG;
-    seg_len = ((seg_len + CS_TILE - 1) / CS_TILE) * CS_TILE;
+    // segments of one LDS tile: the grid is sized by max_M (3 K) but only the blocks below the device-side M do work -- 16 segments
+    // left ~90 active workgroups on 256 CUs
+    int seg_len = CS_TILE;
     dim3 grid((max_M + 255) / 256, (max_M + seg_len - 1) / seg_len);
     hipLaunchKernelGGL(consensus_count_kernel, grid, dim3(256), 0, s, R, t, ss, tt, M_dev, max_M, (float)c->p.inlier_th, seg_len, c->cons_cnt, c->skip);
     hipLaunchKernelGGL(consensus_select_kernel, dim3(1), dim3(1024), 0, s, R, t, ss, tt, M_dev, max_M, (float)c->p.inlier_th, c->cons_cnt,
