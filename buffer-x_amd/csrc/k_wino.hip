@@ -21,8 +21,9 @@
 // Output transform (wino_output): every wave folds its two rows into r_xi[j] = (M0 + M1) + M2 | (M1 - M2) - M3 lane-locally and hands
 // its two quantities -- half 0: r0 + r1 and r1, half 1: r2 and r3 -- to an LDS exchange (bytes of the consumed plane set) that all
 // threads then read in output order: Y[0][j] = ((r0 + r1) + r2), Y[1][j] = ((r1 - r2) - r3), + bias, ReLU, 16-byte stores.
-// Measured and not kept: two units per workgroup, one fat wave per SIMD, the slab write moved behind the
-// transform (3-5 % slower), -fno-slp-vectorize (no change).
+// The two 8-chunk layers run wino_pair_kernel below (two units per workgroup: no padding rows, single-buffered).
+// Measured and not kept: one fat wave per SIMD, the slab write moved behind the transform (3-5 % slower),
+// -fno-slp-vectorize (no change).
 // MFMA work per unit and layer: 16 planes x 3 row tiles against 9 taps x 8.75 row tiles of the direct form (0.61x).
 #include "bx_common.h"
 #include <cstdlib>
@@ -304,6 +305,197 @@ int launch_wino(bx_ctx* c, int layer, hipStream_t s, const ConvLayerDev& L, cons
     BX_LAUNCH_CHECK();
     return BX_OK;
 }
+// ---------------------------------------------------------------------------------------------------- two units per workgroup
+// wino_pair_kernel: the Cylindrical_Net layer with TWO units per workgroup: 2 x 40 tiles fill FIVE MFMA row tiles exactly (the
+// one-unit kernel above pads 40 tiles to 48 rows: one MFMA in six multiplies padding).  Single-buffered slab (2 units) + V planes
+// (16 x 80 rows): 137 KB, two barriers per chunk (the structure of wino_pose_kernel below); wave (ct, half) owns 8 planes x 5 row
+// tiles = 160 accumulator VGPRs.  Used for the layers where it measures faster (bxk_wino).
+constexpr int GP = 2, ROWSP = GP * NT_, RTP = ROWSP / 16, VPLP = ROWSP * ROWF;
+constexpr size_t WINOP_LDS = (size_t)(GP * SLAB_FLOATS + 16 * VPLP) * 4;
+static_assert(ROWSP % 16 == 0 && WINOP_LDS <= 160 * 1024 && 4 * ROWSP * CW <= 16 * VPLP, "two units: five full row tiles, LDS, exchange");
+
+template <int NCHUNK, int COUT, bool RELU>
+__global__ __launch_bounds__(CT, 2) void wino_pair_kernel(const float* __restrict__ in, int units, const float* __restrict__ U,
+                                                          const float* __restrict__ bias, float* __restrict__ out,
+                                                          const int32_t* __restrict__ skip)
+{
+    if (skip && *skip) return;
+    constexpr int NT = COUT / 16;
+    constexpr int NPU = BX_EA * 4, NPIECE = GP * NPU, NLD = (NPIECE + CT - 1) / CT;
+    constexpr int NITEM = 4 * ROWSP * 4, NIT = (NITEM + CT - 1) / CT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* slab = reinterpret_cast<float*>(smem);
+    float* Vp = slab + GP * SLAB_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave & 1, ctl = wave >> 1;
+    const int ctg = (int)blockIdx.y * (CW / 16) + ctl;
+    const int li = lane & 15, kk = lane >> 4;
+    const int ngroups = (units + GP - 1) / GP;
+    if ((int)blockIdx.x >= ngroups) return;
+
+    for (int i = tid; i < (int)(WINOP_LDS / 16); i += CT) reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const float4* in4 = reinterpret_cast<const float4*>(in);
+    float4 st[NLD];
+    auto gload = [&](int ug, int cc) {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int f = tid + q * CT;
+            const int g = f >= NPU ? 1 : 0, fr = f - g * NPU;
+            const int u = ug * GP + g;
+            st[q] = (f < NPIECE && u < units) ? in4[((size_t)u * NCHUNK + cc) * NPU + fr] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lwrite = [&]() {
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int f = tq + q * CT;
+            if (f < NPIECE) {
+                const int g = f >= NPU ? 1 : 0, fr = f - g * NPU;
+                const int p = fr >> 2, part = fr & 3;
+                const int h = p / BX_AZI, w = p - h * BX_AZI;
+                float* d = slab + g * SLAB_FLOATS + ((h + 1) * WP + (w + 1)) * ROWF + part * 4;
+                *reinterpret_cast<float4*>(d) = st[q];
+                if (w == 0) *reinterpret_cast<float4*>(d + BX_AZI * ROWF) = st[q];
+                else if (w == BX_AZI - 1) *reinterpret_cast<float4*>(d - BX_AZI * ROWF) = st[q];
+            }
+        }
+    };
+    int ia[NIT], ib[NIT], iv[NIT];
+    float isg[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int it = tid + k * CT;
+        ia[k] = -1; ib[k] = 0; iv[k] = 0; isg[k] = 0.f;
+        if (it < NITEM) {
+            const int x = it / (ROWSP * 4), rem = it - x * (ROWSP * 4);
+            const int R = rem >> 2, part = rem & 3;
+            const int g = R / NT_, t = R - g * NT_;
+            const int tr = t / TC, tc = t - tr * TC;
+            const int ra = x == 0 ? 0 : (x == 2 ? 2 : 1);
+            const int rb = x == 0 ? 2 : (x == 1 ? 2 : (x == 2 ? 1 : 3));
+            isg[k] = x == 1 ? 1.0f : -1.0f;
+            ia[k] = g * SLAB_FLOATS + ((2 * tr + ra) * WP + 2 * tc) * ROWF + part * 4;
+            ib[k] = g * SLAB_FLOATS + ((2 * tr + rb) * WP + 2 * tc) * ROWF + part * 4;
+            iv[k] = (x * 4) * VPLP + R * ROWF + part * 4;
+        }
+    }
+    auto transform = [&]() {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            if (ia[k] < 0) continue;
+            const float sg = isg[k];
+            float4 tj[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 a = *reinterpret_cast<const float4*>(slab + ia[k] + j * ROWF);
+                const float4 b = *reinterpret_cast<const float4*>(slab + ib[k] + j * ROWF);
+                tj[j] = make_float4(fmaf(sg, b.x, a.x), fmaf(sg, b.y, a.y), fmaf(sg, b.z, a.z), fmaf(sg, b.w, a.w));
+            }
+            float* vd = Vp + iv[k];
+            *reinterpret_cast<float4*>(vd) = make_float4(tj[0].x - tj[2].x, tj[0].y - tj[2].y, tj[0].z - tj[2].z, tj[0].w - tj[2].w);
+            *reinterpret_cast<float4*>(vd + VPLP) = make_float4(tj[1].x + tj[2].x, tj[1].y + tj[2].y, tj[1].z + tj[2].z, tj[1].w + tj[2].w);
+            *reinterpret_cast<float4*>(vd + 2 * VPLP) = make_float4(tj[2].x - tj[1].x, tj[2].y - tj[1].y, tj[2].z - tj[1].z, tj[2].w - tj[1].w);
+            *reinterpret_cast<float4*>(vd + 3 * VPLP) = make_float4(tj[1].x - tj[3].x, tj[1].y - tj[3].y, tj[1].z - tj[3].z, tj[1].w - tj[3].w);
+        }
+    };
+
+    const float* bq = bias + ((int)blockIdx.y * (CW / 16) + ((tid & 15) >> 2)) * 16 + (tid & 3);
+    const float4 b4 = make_float4(bq[0], bq[4], bq[8], bq[12]);
+    const float4* wbase = reinterpret_cast<const float4*>(U) + ((size_t)(half * 8) * NT + ctg) * 64 + lane;
+    const char* abase = reinterpret_cast<const char*>(Vp) + ((half * 8 * ROWSP + li) * ROWF + kk * 4) * 4;
+
+    f32x4 acc[8][RTP];
+    float4 bring[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) bring[p] = wbase[((size_t)p * NT) * 64];
+
+    int ug = blockIdx.x;
+    gload(ug, 0);
+    __syncthreads();
+    lwrite();
+
+    for (;;) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+#pragma unroll
+            for (int rt = 0; rt < RTP; ++rt) acc[p][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int ugn = ug + (int)gridDim.x;
+#pragma unroll 1
+        for (int cc = 0; cc < NCHUNK; ++cc) {
+            __syncthreads();
+            transform();
+            __syncthreads();
+            const bool more = cc + 1 < NCHUNK || ugn < ngroups;
+            if (cc + 1 < NCHUNK) gload(ug, cc + 1);
+            else if (ugn < ngroups) gload(ugn, 0);
+            const int cn = cc + 1 == NCHUNK ? 0 : cc + 1;
+            f32x4 ar[3];
+            ar[0] = *reinterpret_cast<const f32x4*>(abase);
+            ar[1] = *reinterpret_cast<const f32x4*>(abase + (16 * ROWF) * 4);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const float4 bqq = bring[p & 3];
+#pragma unroll
+                for (int rt = 0; rt < RTP; ++rt) {
+                    const int s0 = p * RTP + rt, s2 = s0 + 2;
+                    if (s2 < 8 * RTP) ar[s2 % 3] = *reinterpret_cast<const f32x4*>(abase + (((s2 / RTP) * ROWSP + (s2 % RTP) * 16) * ROWF) * 4);
+                    const f32x4 a = ar[s0 % 3];
+                    acc[p][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bqq.x, acc[p][rt], 0, 0, 0);
+                    acc[p][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bqq.y, acc[p][rt], 0, 0, 0);
+                    acc[p][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bqq.z, acc[p][rt], 0, 0, 0);
+                    acc[p][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bqq.w, acc[p][rt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                bring[p & 3] = p < 4 ? wbase[((size_t)(cc * 16 + p + 4) * NT) * 64] : wbase[((size_t)(cn * 16 + p - 4) * NT) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) lwrite();
+        }
+        __syncthreads();             // every wave is done with the V planes: their bytes carry E now
+        wino_output<RTP, ROWSP, RELU>(acc, Vp, half, ctl, li, kk, tid, b4,
+                                      [&](int R, int j, int quad, const float4& y0, const float4& y1) {
+                                          const int g = R >= NT_ ? 1 : 0, t = R - g * NT_;
+                                          const int u = ug * GP + g;
+                                          if (u < units) {
+                                              const int tr = t / TC, tc = t - tr * TC;
+                                              float* ou = out + ((((size_t)u * NT + (int)blockIdx.y * (CW / 16) + (quad >> 2)) * BX_EA +
+                                                                  (2 * tr) * BX_AZI + 2 * tc + j) * 16 + (quad & 3) * 4);
+                                              *reinterpret_cast<float4*>(ou) = y0;
+                                              if (2 * tr + 1 < BX_ELE) *reinterpret_cast<float4*>(ou + BX_AZI * 16) = y1;
+                                          }
+                                      });
+        ug = ugn;
+        if (ug >= ngroups) break;
+    }
+}
+
+template <int NCHUNK, int COUT, bool RELU>
+int launch_wino_pair(bx_ctx* c, int layer, hipStream_t s, const ConvLayerDev& L, const float* in, int units, float* out)
+{
+    if (L.nchunk != NCHUNK || L.cout != COUT || (L.relu != 0) != RELU || !L.Wwino) {
+        bx_set_error("winograd layer %d: geometry mismatch (%d chunks, %d channels)", layer, L.nchunk, L.cout);
+        return BX_ERR_STATE;
+    }
+    auto k = wino_pair_kernel<NCHUNK, COUT, RELU>;
+    int& cap = c->wino_cap[layer];
+    if (cap == 0) {
+        BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINOP_LDS));
+        cap = c->n_cu / (COUT / CW);
+        if (cap < 1) cap = 1;
+        if (c->conv_cap_override > 0 && c->conv_cap_override < cap) cap = c->conv_cap_override;
+    }
+    int grid = (units + GP - 1) / GP;
+    if (grid <= 0) return BX_OK;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(k, dim3(grid, COUT / CW), dim3(CT), WINOP_LDS, s, in, units, L.Wwino, L.b, out, c->skip);
+    BX_LAUNCH_CHECK();
+    return BX_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------- CostNet layers 1..5
 // CostNet's layers 1..5 (models/patchnet.py:197-201: k(3,3,3) on [18][3][18], then k(3,1,3) on [16][1][16] .. [10][1][10], un-padded)
 // are 2-D valid 3x3 convolutions over (n, l); layer 1 folds its three k rows into the channel dimension (6 effective chunks
@@ -553,6 +745,22 @@ int bxk_wino(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t
 {
     if (units_dev || max_units < 1) return -1;
     const ConvLayerDev& L = c->desc[layer];
+    // bit l = layer l on the two-units-per-workgroup kernel.  Measured per launch (K = 5000, one unit -> two units per workgroup):
+    // 8 chunks 128 -> 128: 1 254 -> 1 184 us, 128 -> 64: 639 -> 594; 4 chunks: 343 -> 337 and 670 -> 670; 3 chunks: 268 -> 275 -- the pair
+    // kernel saves the padding MFMAs but neither overlaps its transform nor amortises its output transform over few chunks: it is
+    // the default for the two 8-chunk layers (BX_WINO_PAIR overrides the mask)
+    static int pair_mask = -1;
+    if (pair_mask < 0) { const char* e = getenv("BX_WINO_PAIR"); pair_mask = e ? atoi(e) : (1 << 3) | (1 << 4); }
+    if ((pair_mask >> layer) & 1) {
+        switch (layer) {
+            case 0: return launch_wino_pair<3, 64, true>(c, layer, s, L, in, max_units, out);
+            case 1: return launch_wino_pair<4, 64, true>(c, layer, s, L, in, max_units, out);
+            case 2: return launch_wino_pair<4, 128, true>(c, layer, s, L, in, max_units, out);
+            case 3: return launch_wino_pair<8, 128, true>(c, layer, s, L, in, max_units, out);
+            case 4: return launch_wino_pair<8, 64, true>(c, layer, s, L, in, max_units, out);
+            case 5: return launch_wino_pair<4, 64, true>(c, layer, s, L, in, max_units, out);
+        }
+    }
     switch (layer) {
         case 0: return launch_wino<3, 64, true>(c, layer, s, L, in, max_units, out);
         case 1: return launch_wino<4, 64, true>(c, layer, s, L, in, max_units, out);

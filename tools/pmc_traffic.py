@@ -25,7 +25,7 @@ def kib(name, which):
 
 
 # Desc stack = the 8 Cylindrical_Net layers (layers 1 and 5 share one instantiation: its mean counts twice)
-desc = [k for k in sec["FETCH"] if (k.startswith("conv_kernel<") and ", 140, 198, 140," in k) or k.startswith("wino_kernel<")]
+desc = [k for k in sec["FETCH"] if (k.startswith("conv_kernel<") and ", 140, 198, 140," in k) or k.startswith("wino_kernel<") or k.startswith("wino_pair_kernel<")]
 tot = 0.0
 detail = {}
 for k in desc:
