@@ -21,7 +21,8 @@
 // Output transform (wino_output): every wave folds its two rows into r_xi[j] = (M0 + M1) + M2 | (M1 - M2) - M3 lane-locally and hands
 // its two quantities -- half 0: r0 + r1 and r1, half 1: r2 and r3 -- to an LDS exchange (bytes of the consumed plane set) that all
 // threads then read in output order: Y[0][j] = ((r0 + r1) + r2), Y[1][j] = ((r1 - r2) - r3), + bias, ReLU, 16-byte stores.
-// The two 8-chunk layers run wino_pair_kernel below (two units per workgroup: no padding rows, single-buffered).
+// By default the layers run wino_pair_kernel below (two units per workgroup: no padding rows, single-buffered); this kernel is the
+// BX_WINO_PAIR=0 form.
 // Measured and not kept: one fat wave per SIMD, the slab write moved behind the transform (3-5 % slower),
 // -fno-slp-vectorize (no change).
 // MFMA work per unit and layer: 16 planes x 3 row tiles against 9 taps x 8.75 row tiles of the direct form (0.61x).
@@ -309,7 +310,8 @@ int launch_wino(bx_ctx* c, int layer, hipStream_t s, const ConvLayerDev& L, cons
 // wino_pair_kernel: the Cylindrical_Net layer with TWO units per workgroup: 2 x 40 tiles fill FIVE MFMA row tiles exactly (the
 // one-unit kernel above pads 40 tiles to 48 rows: one MFMA in six multiplies padding).  Single-buffered slab (2 units) + V planes
 // (16 x 80 rows): 137 KB, two barriers per chunk (the structure of wino_pose_kernel below); wave (ct, half) owns 8 planes x 5 row
-// tiles = 160 accumulator VGPRs.  Used for the layers where it measures faster (bxk_wino).
+// tiles = 160 accumulator VGPRs.  The default for all six Winograd layers (bxk_wino); 5-11 % faster than the one-unit kernel once the
+// slab traffic's addressing is computed once per thread instead of once per chunk.
 constexpr int GP = 2, ROWSP = GP * NT_, RTP = ROWSP / 16, VPLP = ROWSP * ROWF;
 constexpr size_t WINOP_LDS = (size_t)(GP * SLAB_FLOATS + 16 * VPLP) * 4;
 static_assert(ROWSP % 16 == 0 && WINOP_LDS <= 160 * 1024 && 4 * ROWSP * CW <= 16 * VPLP, "two units: five full row tiles, LDS, exchange");
@@ -338,29 +340,39 @@ __global__ __launch_bounds__(CT, 2) void wino_pair_kernel(const float* __restric
 
     const float4* in4 = reinterpret_cast<const float4*>(in);
     float4 st[NLD];
+    // per-thread constants of the slab traffic: piece f = tid + q CT of the group's two units -> source offset inside the group's
+    // [2][NCHUNK][140][16] floats and destination row in the slab (+ the wrap-around copy of azimuth columns 0 / 19); computed once --
+    // recomputing them per chunk was ~100 instructions of integer division per wave and chunk (1 050 cycles in the s_memtime profile)
+    int lsrc[NLD], ldst[NLD], lhalo[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int f = tid + q * CT;
+        lsrc[q] = -1; ldst[q] = 0; lhalo[q] = 0;
+        if (f < NPIECE) {
+            const int g = f >= NPU ? 1 : 0, fr = f - g * NPU;
+            const int p = fr >> 2, part = fr & 3;
+            const int h = p / BX_AZI, w = p - h * BX_AZI;
+            lsrc[q] = g * NCHUNK * NPU + fr;
+            ldst[q] = g * SLAB_FLOATS + ((h + 1) * WP + (w + 1)) * ROWF + part * 4;
+            lhalo[q] = w == 0 ? BX_AZI * ROWF : (w == BX_AZI - 1 ? -BX_AZI * ROWF : 0);
+        }
+    }
     auto gload = [&](int ug, int cc) {
+        const float4* base = in4 + ((size_t)ug * GP * NCHUNK + cc) * NPU;
+        const bool second = ug * GP + 1 < units;               // the last group of an odd unit count has one unit
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
-            const int f = tid + q * CT;
-            const int g = f >= NPU ? 1 : 0, fr = f - g * NPU;
-            const int u = ug * GP + g;
-            st[q] = (f < NPIECE && u < units) ? in4[((size_t)u * NCHUNK + cc) * NPU + fr] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = lsrc[q] >= 0 && (second || lsrc[q] < NCHUNK * NPU);
+            st[q] = ok ? base[lsrc[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto lwrite = [&]() {
-        int tq = tid;
-        asm volatile("" : "+v"(tq));
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
-            const int f = tq + q * CT;
-            if (f < NPIECE) {
-                const int g = f >= NPU ? 1 : 0, fr = f - g * NPU;
-                const int p = fr >> 2, part = fr & 3;
-                const int h = p / BX_AZI, w = p - h * BX_AZI;
-                float* d = slab + g * SLAB_FLOATS + ((h + 1) * WP + (w + 1)) * ROWF + part * 4;
+            if (lsrc[q] >= 0) {
+                float* d = slab + ldst[q];
                 *reinterpret_cast<float4*>(d) = st[q];
-                if (w == 0) *reinterpret_cast<float4*>(d + BX_AZI * ROWF) = st[q];
-                else if (w == BX_AZI - 1) *reinterpret_cast<float4*>(d - BX_AZI * ROWF) = st[q];
+                if (lhalo[q] != 0) *reinterpret_cast<float4*>(d + lhalo[q]) = st[q];
             }
         }
     };
@@ -427,11 +439,15 @@ __global__ __launch_bounds__(CT, 2) void wino_pair_kernel(const float* __restric
 #pragma unroll 1
         for (int cc = 0; cc < NCHUNK; ++cc) {
             __syncthreads();
-            transform();
-            __syncthreads();
+            // the next chunk's slab is requested in front of the transform and written right behind its barrier: the loads have the
+            // transform to land, the registers that carry them are free during the MFMAs, and the write's s_waitcnt vmcnt(0) does
+            // not wait for B fragments requested a moment ago (as it did behind the MFMA loop)
             const bool more = cc + 1 < NCHUNK || ugn < ngroups;
             if (cc + 1 < NCHUNK) gload(ug, cc + 1);
             else if (ugn < ngroups) gload(ugn, 0);
+            transform();
+            __syncthreads();
+            if (more) lwrite();
             const int cn = cc + 1 == NCHUNK ? 0 : cc + 1;
             f32x4 ar[3];
             ar[0] = *reinterpret_cast<const f32x4*>(abase);
@@ -453,7 +469,6 @@ __global__ __launch_bounds__(CT, 2) void wino_pair_kernel(const float* __restric
                 bring[p & 3] = p < 4 ? wbase[((size_t)(cc * 16 + p + 4) * NT) * 64] : wbase[((size_t)(cn * 16 + p - 4) * NT) * 64];
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (more) lwrite();
         }
         __syncthreads();             // every wave is done with the V planes: their bytes carry E now
         wino_output<RTP, ROWSP, RELU>(acc, Vp, half, ctl, li, kk, tid, b4,
@@ -745,12 +760,11 @@ int bxk_wino(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t
 {
     if (units_dev || max_units < 1) return -1;
     const ConvLayerDev& L = c->desc[layer];
-    // bit l = layer l on the two-units-per-workgroup kernel.  Measured per launch (K = 5000, one unit -> two units per workgroup):
-    // 8 chunks 128 -> 128: 1 254 -> 1 184 us, 128 -> 64: 639 -> 594; 4 chunks: 343 -> 337 and 670 -> 670; 3 chunks: 268 -> 275 -- the pair
-    // kernel saves the padding MFMAs but neither overlaps its transform nor amortises its output transform over few chunks: it is
-    // the default for the two 8-chunk layers (BX_WINO_PAIR overrides the mask)
+    // bit l = layer l on the two-units-per-workgroup kernel (default: all six; BX_WINO_PAIR=0 selects the one-unit pipelined
+    // kernel).  Measured per launch (K = 5000, one unit -> two units per workgroup): 3 chunks 268 -> 257 us; 4 chunks 343 -> 317 and
+    // 670 -> 627; 8 chunks 128 -> 128: 1 254 -> 1 131, 128 -> 64: 639 -> 566
     static int pair_mask = -1;
-    if (pair_mask < 0) { const char* e = getenv("BX_WINO_PAIR"); pair_mask = e ? atoi(e) : (1 << 3) | (1 << 4); }
+    if (pair_mask < 0) { const char* e = getenv("BX_WINO_PAIR"); pair_mask = e ? atoi(e) : 63; }
     if ((pair_mask >> layer) & 1) {
         switch (layer) {
             case 0: return launch_wino_pair<3, 64, true>(c, layer, s, L, in, max_units, out);

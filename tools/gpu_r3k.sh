@@ -1,23 +1,24 @@
 #!/bin/bash
-# round 3, call K: two-units-per-workgroup Winograd kernel (BX_WINO_PAIR = layer mask) -- parity + per-kernel time
+# round 3, call K: Winograd kernels -- parity + per-kernel time + rate
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/r3k; rm -rf $OUT; mkdir -p $OUT
-BX_WINO_PAIR=63 timeout 600 python -m pytest tests/test_gpu_stages.py -x -q -k "desc_conv_layer_exact or desc_net" 2>&1 | tail -3
-BX_WINO_PAIR=63 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --latency-tiles 0 --e2e-pairs 0 > $OUT/bench_kt.log 2>&1
+timeout 600 python -m pytest tests/test_gpu_stages.py -x -q -k "desc_conv_layer_exact or desc_net or pose" 2>&1 | tail -3
+BX_WINO_PAIR=0 timeout 600 python -m pytest tests/test_gpu_stages.py -x -q -k "desc_conv_layer_exact or desc_net" 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_gpu_headline.py tests/test_gpu_pipeline.py -x -q 2>&1 | tail -3
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --latency-tiles 0 --e2e-pairs 0 > $OUT/bench_kt.log 2>&1
 python - <<'PY'
 import glob, sqlite3
 for f in sorted(glob.glob("gpurun_out/r3k/kt/**/*.db", recursive=True)):
     db = sqlite3.connect(f)
     for name, calls, tot, avg, pct in db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
-        if "wino_pair" in name or "wino_kernel" in name:
+        if "wino" in name:
             n = name.replace("(anonymous namespace)::", "").replace("void ", "")
             print("%-60s %5d %10.1f us" % (n[:n.find("(")], calls, avg / 1e3 if avg > 1e5 else avg))
 PY
-for m in 0 24 63; do BX_WINO_PAIR=$m python bench.py --steps 24 --warmup 8 --no-cpu-baseline --latency-tiles 0 --e2e-pairs 0 > $OUT/bench_$m.json 2> $OUT/bench_$m.err; python - $OUT/bench_$m.json $m <<'PY'
+python bench.py --steps 24 --warmup 8 --no-cpu-baseline --latency-tiles 0 --e2e-pairs 0 > $OUT/bench.json 2> $OUT/bench.err; python - $OUT/bench.json <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); s = d["stages_ms_per_pair"]
-print("mask", sys.argv[2], "value", d["value"], "desc", s.get("desc_conv"), "ok", d["registered_ok"])
+print("value", d["value"], "desc", s.get("desc_conv"), "pose", s.get("pose_net"), "ok", d["registered_ok"], "roofline", d["roofline"]["frac"], d["roofline"]["executed_frac"])
 PY
-done
 find $OUT -name '*.csv' -size +2M -delete; find $OUT -name '*.db' -size +20M -delete
