@@ -102,10 +102,11 @@ __global__ __launch_bounds__(PF_THREADS) void patch_features_kernel(
     if (tr) { t0 = __builtin_readcyclecounter(); td[0] = t0; }
 #define PF_TR(k) do { if (tr) td[k] = __builtin_readcyclecounter() - t0; } while (0)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* sp = reinterpret_cast<float4*>(smem);                             // [P] x, y, z, sqrt(x^2 + y^2)
-    unsigned short* shit = reinterpret_cast<unsigned short*>(sp + P);        // [nsample][BX_VOX]
+    float4* sp = reinterpret_cast<float4*>(smem);                             // [P + 1] x, y, z, sqrt(x^2 + y^2); entry P = a point far away
+    unsigned short* shit = reinterpret_cast<unsigned short*>(sp + P + 1);    // [nsample][BX_VOX]
     int* rlen = reinterpret_cast<int*>(shit + (size_t)nsample * BX_VOX);     // [32] candidates per (shell, elevation) row
     unsigned short* rlist = reinterpret_cast<unsigned short*>(rlen + 32);    // [NROWS][cap] candidate point indices, ascending
+    unsigned short* far8 = rlist + (size_t)NROWS * cap + 8;                   // eight copies of index P (behind the 16-byte read slack)
 
     const int q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -132,6 +133,9 @@ __global__ __launch_bounds__(PF_THREADS) void patch_features_kernel(
         const float px = nx / des_r, py = ny / des_r;
         sp[i] = make_float4(px, py, nzc / des_r, sqrtf(px * px + py * py));
     }
+    // the far point: a list entry P never passes the distance test, so list tails and idle lanes need no per-candidate bounds checks
+    if (tid == 0) sp[P] = make_float4(1.0e30f, 1.0e30f, 1.0e30f, 1.0e30f);
+    if (tid < 8) far8[tid] = (unsigned short)P;
     __syncthreads();
     PF_TR(1);
 
@@ -178,6 +182,15 @@ __global__ __launch_bounds__(PF_THREADS) void patch_features_kernel(
                 if (row < NROWS) rlen[row] = base[r] <= cap ? base[r] : -1;
             }
         }
+        // pad every list to a multiple of 8 entries with the far point (cap is a multiple of 8)
+        if (lane < 8) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int row = wave + r * PF_WAVES;
+                if (row < NROWS && base[r] <= cap && base[r] + lane < ((base[r] + 7) & ~7))
+                    rlist[(size_t)row * cap + base[r] + lane] = (unsigned short)P;
+            }
+        }
     }
     __syncthreads();
     PF_TR(2);
@@ -197,33 +210,57 @@ __global__ __launch_bounds__(PF_THREADS) void patch_features_kernel(
         const int len = act ? (full ? P : rl_len) : 0;
         const unsigned short* rl = rlist + (size_t)row * cap;
         int cnt = 0;
-        for (int i0 = 0; ; i0 += 8) {
-            if (__all(cnt >= nsample || i0 >= len)) break;
-            const uint4 kq = *reinterpret_cast<const uint4*>(rl + i0);
-            int ks[8];
-            ks[0] = kq.x & 0xffff; ks[1] = kq.x >> 16; ks[2] = kq.y & 0xffff; ks[3] = kq.y >> 16;
-            ks[4] = kq.z & 0xffff; ks[5] = kq.z >> 16; ks[6] = kq.w & 0xffff; ks[7] = kq.w >> 16;
-            unsigned hm = 0;
+        // the hits of a step, in list order, up to nsample (a macro: a lambda taking ks[] by reference sends the array to scratch)
+#define PF_RECORD(hm, ks)                                                       \
+        while (hm != 0u && cnt < nsample) {                                     \
+            const int j_ = __ffs((int)hm) - 1;                                  \
+            int k_ = ks[0];                                                     \
+            _Pragma("unroll") for (int u = 1; u < 8; ++u) k_ = (j_ == u) ? ks[u] : k_; \
+            shit[cnt * BX_VOX + v] = (unsigned short)k_;                        \
+            ++cnt;                                                              \
+            hm &= hm - 1u;                                                      \
+        }
+        if (!__any(full)) {
+            // the common case: every row of the wave has a list.  Lists are padded with the far point and a lane whose list has
+            // ended reads eight far points, so a candidate costs its index unpack, one LDS read, the distance and one compare
+            for (int i0 = 0; ; i0 += 8) {
+                if (__all(cnt >= nsample || i0 >= len)) break;
+                const uint4 kq = *reinterpret_cast<const uint4*>(i0 < len ? rl + i0 : far8);
+                int ks[8];
+                ks[0] = kq.x & 0xffff; ks[1] = kq.x >> 16; ks[2] = kq.y & 0xffff; ks[3] = kq.y >> 16;
+                ks[4] = kq.z & 0xffff; ks[5] = kq.z >> 16; ks[6] = kq.w & 0xffff; ks[7] = kq.w >> 16;
+                unsigned hm = 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                int k = full ? i0 + j : ks[j];
-                k = k < P ? k : P - 1;
-                ks[j] = k;
-                const float4 d = sp[k];
-                const float dx = qx - d.x, dy = qy - d.y, dz = qz - d.z;
-                const float dd = (dx * dx + dy * dy) + dz * dz;
-                if (dd < vr2 && i0 + j < len) hm |= 1u << j;
+                for (int j = 0; j < 8; ++j) {
+                    const float4 d = sp[ks[j]];
+                    const float dx = qx - d.x, dy = qy - d.y, dz = qz - d.z;
+                    const float dd = (dx * dx + dy * dy) + dz * dz;
+                    if (dd < vr2) hm |= 1u << j;
+                }
+                PF_RECORD(hm, ks)
             }
-            while (hm != 0u && cnt < nsample) {
-                const int j = __ffs((int)hm) - 1;
-                int k = ks[0];
+        } else {
+            for (int i0 = 0; ; i0 += 8) {
+                if (__all(cnt >= nsample || i0 >= len)) break;
+                const uint4 kq = *reinterpret_cast<const uint4*>(rl + i0);
+                int ks[8];
+                ks[0] = kq.x & 0xffff; ks[1] = kq.x >> 16; ks[2] = kq.y & 0xffff; ks[3] = kq.y >> 16;
+                ks[4] = kq.z & 0xffff; ks[5] = kq.z >> 16; ks[6] = kq.w & 0xffff; ks[7] = kq.w >> 16;
+                unsigned hm = 0;
 #pragma unroll
-                for (int u = 1; u < 8; ++u) k = (j == u) ? ks[u] : k;
-                shit[cnt * BX_VOX + v] = (unsigned short)k;
-                ++cnt;
-                hm &= hm - 1u;
+                for (int j = 0; j < 8; ++j) {
+                    int k = full ? i0 + j : ks[j];
+                    k = k < P ? k : P - 1;
+                    ks[j] = k;
+                    const float4 d = sp[k];
+                    const float dx = qx - d.x, dy = qy - d.y, dz = qz - d.z;
+                    const float dd = (dx * dx + dy * dy) + dz * dz;
+                    if (dd < vr2 && i0 + j < len) hm |= 1u << j;
+                }
+                PF_RECORD(hm, ks)
             }
         }
+#undef PF_RECORD
         PF_TR(3);
         if (!act) continue;
         const int a = v % BX_AZI;
@@ -265,7 +302,7 @@ int bxk_patch_features(bx_ctx* c, hipStream_t s, const float* patches, int K, in
     const int ns = c->p.voxel_sample;
     if (ns < 1 || ns > MAX_NS || P < 2 || P > 8192) { bx_set_error("bxk_patch_features: voxel_sample=%d P=%d unsupported", ns, P); return BX_ERR_ARG; }
     int cap = ((P / 2 + 7) / 8) * 8 + 8;                      // row-list capacity (multiple of 8, one 16-byte read of slack)
-    size_t lds = (size_t)P * 16 + (size_t)ns * BX_VOX * 2 + 128 + (size_t)NROWS * cap * 2 + 16;
+    size_t lds = (size_t)(P + 1) * 16 + (size_t)ns * BX_VOX * 2 + 128 + (size_t)NROWS * cap * 2 + 16 + 16;   // + far point, + far8
     if (lds > 160 * 1024) { bx_set_error("bxk_patch_features: P=%d needs %zu B of LDS", P, lds); return BX_ERR_ARG; }
     if (lds > 64 * 1024 && !c->patch_attr_set) {
         BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(patch_features_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
