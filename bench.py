@@ -39,6 +39,8 @@ DESC_CONV_MMAC_PER_PATCH = 3.871 + 5.161 + 10.322 + 20.644 + 10.322 + 5.161 + 2.
 # -- 16 planes x 48 tile rows (40 used) per unit instead of 9 taps x 140 positions: 768 / 1260 of the direct MACs -- layers 6, 7 direct
 # (two units per workgroup: 16 planes x 40 tile rows, no padding: 640 / 1260 of the direct MACs)
 DESC_WINO_EXECUTED_MMAC_PER_PATCH = (3.871 + 5.161 + 10.322 + 20.644 + 10.322 + 5.161) * 640.0 / 1260.0 + 2.580 + 1.290
+# F(4x4, 3x3), the default since the end of round 3: 36 planes x 32 tile rows (30 used) per three units = 384 / 1260 of the direct MACs
+DESC_WINO43_EXECUTED_MMAC_PER_PATCH = (3.871 + 5.161 + 10.322 + 20.644 + 10.322 + 5.161) * 384.0 / 1260.0 + 2.580 + 1.290
 COSTNET_MMAC_PER_MATCH = 80.0    # the reference's CostNet on the materialised 20-shift cost volume
 # what the shipped kernels execute: layer 0 collapsed to its P - Q form (k_cost.hip: 1.42 MMAC of binary64 VALU work instead of the
 # 26.87 MMAC fp32 convolution of the volume); the remaining 53.1 MMAC of layers 1..9 are f32 MFMA work
@@ -339,16 +341,19 @@ def main():
         if conv_n:
             conv_n = max(1, int(round(conv_n * ran)))
             ach = flops_per_stack / (conv_ms / conv_n * 1e-3) / 1e12
-            wino = os.environ.get("BX_DESC_CONV", "winograd") != "direct"
-            ex_mmac = DESC_WINO_EXECUTED_MMAC_PER_PATCH if wino else DESC_CONV_MMAC_PER_PATCH
+            form = os.environ.get("BX_DESC_CONV", "winograd43")
+            wino = form != "direct"
+            w43 = form not in ("direct", "winograd")
+            ex_mmac = DESC_WINO43_EXECUTED_MMAC_PER_PATCH if w43 else (DESC_WINO_EXECUTED_MMAC_PER_PATCH if wino else DESC_CONV_MMAC_PER_PATCH)
             ex_ach = 2.0 * ex_mmac * 1e6 * K / (conv_ms / conv_n * 1e-3) / 1e12
-            roof = {"kernel": ("wino_pair_kernel<...> x6 (Winograd F(2x2,3x3), two units per workgroup) + conv_kernel<...> x2" if wino else "conv_kernel<...> x8") + " (Cylindrical_Net stack, f32 MFMA)",
+            roof = {"kernel": ("wino43_kernel<...> x6 (Winograd F(4x4,3x3), three units per workgroup) + conv_kernel<...> x2" if w43 else
+                               "wino_pair_kernel<...> x6 (Winograd F(2x2,3x3), two units per workgroup) + conv_kernel<...> x2" if wino else "conv_kernel<...> x8") + " (Cylindrical_Net stack, f32 MFMA)",
                     "bound": "mfma",
                     "achieved": round(ach, 3), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F32_MATRIX_TFLOPS, 4),
                     "frac_note": "ALGORITHMIC flops of the layers (59.35 MMAC per patch, SURVEY.md App. B: what the reference's cuDNN convolution "
-                                 "multiplies) over the measured time" + ("; the Winograd layers issue 640 / 1260 of those multiplications, so this figure "
-                                 "is an algorithm-adjusted rate, not matrix-pipe utilisation: see executed_*" if wino else ""),
+                                 "multiplies) over the measured time" + (("; the Winograd layers issue %s / 1260 of those multiplications, so this figure "
+                                 "is an algorithm-adjusted rate, not matrix-pipe utilisation: see executed_*") % ("384" if w43 else "640") if wino else ""),
                     "executed_flops_per_launch": 2.0 * ex_mmac * 1e6 * K, "executed_achieved": round(ex_ach, 3),
                     "executed_frac": round(ex_ach / PEAK_F32_MATRIX_TFLOPS, 4),
                     "traffic": pmc["desc_conv_stack_bytes_per_launch"] if fresh(pmc) else None,

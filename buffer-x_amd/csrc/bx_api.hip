@@ -393,7 +393,7 @@ static int create_impl(bx_ctx* c, int device_id)
         // direct form) or BX_DESC_CONV=direct (conv_kernel of k_conv.hip).  The two forms have different arithmetic contracts
         // (oracle: bxo_conv_wino / bxo_conv); oracle/oracle.py follows the same variable.
         e = getenv("BX_DESC_CONV");
-        c->use_wino = (e && strcmp(e, "direct") == 0) ? 0 : 1;
+        c->use_wino = (e && strcmp(e, "direct") == 0) ? 0 : ((e && strcmp(e, "winograd") == 0) ? 1 : 2);   // default: winograd43
         e = getenv("BX_POSE_CONV");
         c->use_wino_pose = (e && strcmp(e, "direct") == 0) ? 0 : 1;
         e = getenv("BX_EXP_SPLIT_CONV");
@@ -519,7 +519,7 @@ int bx_destroy(bx_ctx* c)
     (void)hipFree(c->d_cost_wp); (void)hipFree(c->d_cost_wq);
     (void)hipFree(c->d_centres); (void)hipFree(c->d_rot); (void)hipFree(c->d_rowc); (void)hipFree(c->d_rad_thr);
     (void)hipFree(c->d_pnt_w); (void)hipFree(c->d_pnt_b); (void)hipFree(c->d_pool_w1); (void)hipFree(c->d_pool_b1); (void)hipFree(c->d_pool_w2); (void)hipFree(c->d_pool_b2);
-    for (int i = 0; i < BX_NDESC; ++i) { (void)hipFree(c->desc[i].W); (void)hipFree(c->desc[i].W32); (void)hipFree(c->desc[i].Wwino); (void)hipFree(c->desc[i].Wsplit); (void)hipFree(c->desc[i].b); (void)hipFree(c->desc[i].lrow); (void)hipFree(c->desc[i].lrow2); (void)hipFree(c->desc[i].obase); (void)hipFree(c->desc[i].toff); }
+    for (int i = 0; i < BX_NDESC; ++i) { (void)hipFree(c->desc[i].W); (void)hipFree(c->desc[i].W32); (void)hipFree(c->desc[i].Wwino); (void)hipFree(c->desc[i].Wwino43); (void)hipFree(c->desc[i].Wsplit); (void)hipFree(c->desc[i].b); (void)hipFree(c->desc[i].lrow); (void)hipFree(c->desc[i].lrow2); (void)hipFree(c->desc[i].obase); (void)hipFree(c->desc[i].toff); }
     for (int i = 0; i < BX_NPOSE; ++i) { (void)hipFree(c->pose[i].W); (void)hipFree(c->pose[i].Wwino); (void)hipFree(c->pose[i].b); (void)hipFree(c->pose[i].lrow); (void)hipFree(c->pose[i].lrow2); (void)hipFree(c->pose[i].obase); (void)hipFree(c->pose[i].toff); }
     delete c;
     return BX_OK;
@@ -643,6 +643,7 @@ int bx_load_weights(bx_ctx* c, const bx_weights* w)
         if ((rc = upload_w(L, w->desc_w[l])) != BX_OK) return rc;
         if ((rc = upload_w32(L, w->desc_w[l])) != BX_OK) return rc;
         if ((rc = bxk_wino_weights(w->desc_w[l], L.nchunk, 1, L.cout, &L.Wwino)) != BX_OK) return rc;
+        if (c->use_wino == 2 && L.cout >= 64 && (rc = bxk_wino43_weights(w->desc_w[l], L.nchunk, L.cout, &L.Wwino43)) != BX_OK) return rc;
         if (l == 3 && c->exp_split && (rc = bxk_split_weights(w->desc_w[l], L.nchunk, L.cout, &L.Wsplit)) != BX_OK) return rc;
         if ((rc = upload(&L.b, w->desc_b[l], (size_t)L.cout)) != BX_OK) return rc;
         if ((rc = upload_geo(L, cg)) != BX_OK) return rc;

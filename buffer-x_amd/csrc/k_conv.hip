@@ -562,6 +562,10 @@ int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, cons
         const int rcs = bxk_split_conv(c, s, layer, in, units_dev, max_units, out);   // measurement only (k_split.hip)
         if (rcs >= 0) return rcs;
     }
+    if (net == 0 && c->use_wino == 2) {
+        const int rc43 = bxk_wino43(c, s, layer, in, units_dev, max_units, out);
+        if (rc43 >= 0) return rc43;
+    }
     if (net == 0 && c->use_wino) {
         const int rcw = bxk_wino(c, s, layer, in, units_dev, max_units, out);
         if (rcw >= 0) return rcw;

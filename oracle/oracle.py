@@ -156,6 +156,18 @@ def conv_wino(x, W, bias, relu, ele_n=7, azi_n=20):
     return out
 
 
+def conv_wino43(x, W, bias, relu, ele_n=7, azi_n=20):
+    """Cylindrical 3x3 layer as Winograd F(4x4, 3x3) (bxo_conv_wino43).  x [units][n_chunks][ele*azi][16]; W [n_chunks][9][16][cout]."""
+    x, W, bias = _f(x), _f(W), _f(bias)
+    units, n_chunks, p_in, _ = x.shape
+    cout = W.shape[-1]
+    assert p_in == ele_n * azi_n and azi_n % 4 == 0 and W.shape == (n_chunks, 9, 16, cout)
+    out = np.zeros((units, (cout + 15) // 16, p_in, 16), np.float32)
+    lib().bxo_conv_wino43(_p(x), C.c_int(units), C.c_int(n_chunks), C.c_int(ele_n), C.c_int(azi_n), _p(W), _p(bias), C.c_int(cout),
+                          C.c_int(int(relu)), _p(out))
+    return out
+
+
 def conv_wino_valid(x, W, bias, relu, D, fold):
     """CostNet layer as a valid Winograd F(2x2, 3x3) convolution over a D x D map (bxo_conv_wino_valid); fold = 3 for the k(3,3,3)
     layer (its three k rows become input channels), 1 for the k(3,1,3) layers.  x [units][n_chunks][D*fold*D][16]."""
@@ -183,14 +195,17 @@ def pose_conv(layer, x, tap, dims, W, bias, relu):
 
 # which restatement of the Cylindrical_Net layers the chain and the tests use -- it follows the product's switch (BX_DESC_CONV,
 # read by bx_create): "winograd" (default) = bxo_conv_wino (k_wino.hip), "direct" = fmaf chain over chunk > tap > channel (conv_kernel, k_conv.hip)
-DESC_CONV = os.environ.get("BX_DESC_CONV", "winograd")
+DESC_CONV = os.environ.get("BX_DESC_CONV", "winograd43")
 
 
 def desc_conv(x, tap, W, bias, relu):
     """One Cylindrical_Net layer in the arithmetic the product is configured for (k_wino.hip serves the layers with >= 64 output
     channels; the two 32-channel layers stay on the direct kernels in either mode)."""
-    if DESC_CONV == "winograd" and np.asarray(W).shape[-1] >= 64:
-        return conv_wino(x, W, bias, relu)
+    if np.asarray(W).shape[-1] >= 64:
+        if DESC_CONV == "winograd":
+            return conv_wino(x, W, bias, relu)          # F(2x2, 3x3)
+        if DESC_CONV != "direct":
+            return conv_wino43(x, W, bias, relu)        # F(4x4, 3x3), the default
     return conv(x, tap, W, bias, relu)
 
 

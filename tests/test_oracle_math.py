@@ -167,6 +167,25 @@ def test_winograd_layers_close_to_direct_form(oracle, bx, packed):
         assert np.abs(oracle.conv(x, tap, L["W"], L["b"], True) - oracle.conv_wino(x, L["W"], L["b"], True)).max() < 1e-5
 
 
+def test_winograd43_layers_close_to_direct_form(oracle, bx, packed):
+    """bxo_conv_wino43 (F(4x4, 3x3), the contract of k_wino43.hip and the default form of the >= 64-channel layers) against bxo_conv:
+    the same layer up to re-association and the amplification of the F(4x4) transforms (<= 1e-4 absolute on values of O(5); measured
+    ~3e-5: tests/study_wino43_error.py); all 140 positions (elevation padding, wrap-around, the dropped 8th output row)."""
+    rng = np.random.default_rng(0)
+    tap = bx.weights.cyl_tap_table()
+    x = np.abs(rng.standard_normal((4, 3, 140, 16))).astype(np.float32)     # 4 units: one full group of three + a group of one
+    for L in packed["desc"]:
+        a = oracle.conv(x, tap, L["W"], L["b"], L["relu"])
+        b = oracle.conv_wino43(x, L["W"], L["b"], L["relu"])
+        assert a.shape == b.shape and np.abs(a - b).max() < 1e-4 * max(1.0, float(np.abs(a).max()) / 5.0)
+        x = a
+    L = packed["desc"][1]
+    for p in (0, 3, 19, 20, 79, 83, 120, 139):
+        x = np.zeros((1, 4, 140, 16), np.float32)
+        x[0, :, p, :] = 1.0
+        assert np.abs(oracle.conv(x, tap, L["W"], L["b"], True) - oracle.conv_wino43(x, L["W"], L["b"], True)).max() < 2e-5
+
+
 def test_collapsed_cost_layer_close_to_direct_form(oracle, bx, packed):
     """bxo_cost_l0 (binary64 P - Q form, the contract of k_cost.hip) against the fp32 convolution of the materialised cost volume
     (CostVolume.forward + the first Conv3d, models/BUFFERX.py:59-65, models/patchnet.py:196), incl. nearly equal maps (P - Q cancels)."""

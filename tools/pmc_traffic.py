@@ -25,11 +25,11 @@ def kib(name, which):
 
 
 # Desc stack = the 8 Cylindrical_Net layers (layers 1 and 5 share one instantiation: its mean counts twice)
-desc = [k for k in sec["FETCH"] if (k.startswith("conv_kernel<") and ", 140, 198, 140," in k) or k.startswith("wino_kernel<") or k.startswith("wino_pair_kernel<")]
+desc = [k for k in sec["FETCH"] if (k.startswith("conv_kernel<") and ", 140, 198, 140," in k) or k.startswith("wino_kernel<") or k.startswith("wino_pair_kernel<") or k.startswith("wino43_kernel<")]
 tot = 0.0
 detail = {}
 for k in desc:
-    mult = 2 if (k.startswith("conv_kernel<4, 9, 140, 198, 140, 64,") or k.startswith("wino_kernel<4, 64,")) else 1   # layers 1 and 5 share an instantiation
+    mult = 2 if (k.startswith("conv_kernel<4, 9, 140, 198, 140, 64,") or k.startswith("wino_kernel<4, 64,") or k.startswith("wino_pair_kernel<4, 64,") or k.startswith("wino43_kernel<4, 64,")) else 1   # layers 1 and 5 share an instantiation
     b = (2.0 * kib(k, "FETCH")[1] + kib(k, "WRITE")[1]) * 1024.0
     detail[k] = {"fetch_KiB_raw": kib(k, "FETCH")[1], "write_KiB": kib(k, "WRITE")[1], "bytes": b, "layers": mult}
     tot += mult * b
