@@ -206,11 +206,15 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
 #pragma unroll 1
         for (int cc = 0; cc < NCHUNK; ++cc) {
             __syncthreads();         // slab of chunk cc in place; every wave is done with the V planes of the chunk before
-            transform();
-            __syncthreads();         // V complete; the slab is free
+            // the next slab is requested in front of the transform and written right behind its barrier: by then these loads AND the B
+            // fragments requested at the end of the previous MFMA phase have landed (behind the MFMA loop the write's s_waitcnt vmcnt(0)
+            // waited an L2 round trip for fragments requested a moment earlier: 1 500-2 000 cycles per chunk in the s_memtime profile)
             const bool more = cc + 1 < NCHUNK || ugn < ngroups;
             if (cc + 1 < NCHUNK) gload(ug, cc + 1);
             else if (ugn < ngroups) gload(ugn, 0);
+            transform();
+            __syncthreads();         // V complete; the slab is free
+            if (more) lwrite();
             const int cn = cc + 1 == NCHUNK ? 0 : cc + 1;
             f32x4 ar[3];
             ar[0] = *reinterpret_cast<const f32x4*>(abase);
@@ -232,7 +236,6 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
                 bring[p % 3] = p + 3 < NPH ? wbase[((size_t)(cc * NPL + p + 3) * NT) * 64] : wbase[((size_t)(cn * NPL + p + 3 - NPH) * NT) * 64];
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (more) lwrite();
         }
         __syncthreads();             // every wave is done with the V planes: their bytes carry the exchange now
 
