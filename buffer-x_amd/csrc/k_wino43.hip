@@ -104,7 +104,11 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
         const float4* base = in4 + ((size_t)ug * G4 * NCHUNK + cc) * NPU;
         const int lim = (units - ug * G4) * NCHUNK * NPU;       // pieces of units that do not exist read as zeros
 #pragma unroll
-        for (int q = 0; q < NLD; ++q) st[q] = (lsrc[q] >= 0 && lsrc[q] < lim) ? base[lsrc[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < NLD; ++q) {
+            // streamed once: non-temporal, so that the activations do not push the B fragments (re-read by every workgroup) out of L2
+            const f32x4 v = (lsrc[q] >= 0 && lsrc[q] < lim) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + lsrc[q])) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            st[q] = make_float4(v.x, v.y, v.z, v.w);
+        }
     };
     auto lwrite = [&]() {
 #pragma unroll
@@ -222,6 +226,9 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
 #pragma unroll
             for (int p = 0; p < NPH; ++p) {
                 const float4 bqq = bring[p % 3];
+                // the slot is refilled BEFORE the plane's MFMAs (they read the copy): four planes of look-ahead from a ring of three
+                bring[p % 3] = p + 3 < NPH ? wbase[((size_t)(cc * NPL + p + 3) * NT) * 64] : wbase[((size_t)(cn * NPL + p + 3 - NPH) * NT) * 64];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int rt = 0; rt < RT4; ++rt) {
                     const int s0 = p * RT4 + rt, s2 = s0 + 2;
@@ -233,8 +240,6 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
                     acc[p][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bqq.w, acc[p][rt], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                bring[p % 3] = p + 3 < NPH ? wbase[((size_t)(cc * NPL + p + 3) * NT) * 64] : wbase[((size_t)(cn * NPL + p + 3 - NPH) * NT) * 64];
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();             // every wave is done with the V planes: their bytes carry the exchange now
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
                     const float4 p1 = *reinterpret_cast<const float4*>(e + ((4 + j) * VR4) * 64);
                     float4 y = make_float4((p0.x + p1.x) + b4.x, (p0.y + p1.y) + b4.y, (p0.z + p1.z) + b4.z, (p0.w + p1.w) + b4.w);
                     if (RELU) y = make_float4(y.x > 0.f ? y.x : 0.f, y.y > 0.f ? y.y : 0.f, y.z > 0.f ? y.z : 0.f, y.w > 0.f ? y.w : 0.f);
-                    *reinterpret_cast<float4*>(ou + j * 16) = y;
+                    __builtin_nontemporal_store((f32x4){y.x, y.y, y.z, y.w}, reinterpret_cast<f32x4*>(ou + j * 16));
                 }
             }
             __syncthreads();
