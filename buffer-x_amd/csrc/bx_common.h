@@ -262,6 +262,20 @@ int bxk_refine(bx_ctx* c, hipStream_t s, const float* ss, const float* tt, const
 
 #ifdef __HIPCC__
 // ------------------------------------------------------------------ device helpers
+// Streamed-once activations (a layer's input map, its output map) bypass the L2 retention policy: with plain loads / stores the ~360 MB
+// a layer moves evict the few MB of weight fragments every workgroup re-reads, and the MFMA loops wait for them at Infinity-Cache
+// latency (round 3: -12 % per convolution kernel, measured on k_wino43.hip first).
+__device__ __forceinline__ float4 bx_ld_stream(const float4* p)
+{
+    typedef float bx_f32x4 __attribute__((ext_vector_type(4)));
+    const bx_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const bx_f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void bx_st_stream(float4* p, const float4& y)
+{
+    typedef float bx_f32x4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store((bx_f32x4){y.x, y.y, y.z, y.w}, reinterpret_cast<bx_f32x4*>(p));
+}
 __host__ __device__ __forceinline__ uint64_t bx_mix64(uint64_t seed, uint64_t ctr)
 {
     uint64_t z = seed + 0x9E3779B97F4A7C15ULL * (ctr + 1);

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(CT, 2) void wino_kernel(const float* __restrict__ i
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
             const int f = tid + q * CT;
-            st[q] = f < NPIECE ? in4[((size_t)u * NCHUNK + cc) * NPIECE + f] : make_float4(0.f, 0.f, 0.f, 0.f);
+            st[q] = f < NPIECE ? bx_ld_stream(in4 + ((size_t)u * NCHUNK + cc) * NPIECE + f) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto lwrite = [&](int g) {
@@ -276,8 +276,8 @@ __global__ __launch_bounds__(CT, 2) void wino_kernel(const float* __restrict__ i
                                       const int tr = R / TC, tc = R - tr * TC;
                                       float* ou = out + ((((size_t)u * NT + (int)blockIdx.y * (CW / 16) + (quad >> 2)) * BX_EA +
                                                           (2 * tr) * BX_AZI + 2 * tc + j) * 16 + (quad & 3) * 4);
-                                      *reinterpret_cast<float4*>(ou) = y0;
-                                      if (2 * tr + 1 < BX_ELE) *reinterpret_cast<float4*>(ou + BX_AZI * 16) = y1;
+                                      bx_st_stream(reinterpret_cast<float4*>(ou), y0);
+                                      if (2 * tr + 1 < BX_ELE) bx_st_stream(reinterpret_cast<float4*>(ou + BX_AZI * 16), y1);
                                   });
     }
 }
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(CT, 2) void wino_pair_kernel(const float* __restric
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
             const bool ok = lsrc[q] >= 0 && (second || lsrc[q] < NCHUNK * NPU);
-            st[q] = ok ? base[lsrc[q]] : make_float4(0.f, 0.f, 0.f, 0.f);
+            st[q] = ok ? bx_ld_stream(base + lsrc[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto lwrite = [&]() {
@@ -479,8 +479,8 @@ __global__ __launch_bounds__(CT, 2) void wino_pair_kernel(const float* __restric
                                               const int tr = t / TC, tc = t - tr * TC;
                                               float* ou = out + ((((size_t)u * NT + (int)blockIdx.y * (CW / 16) + (quad >> 2)) * BX_EA +
                                                                   (2 * tr) * BX_AZI + 2 * tc + j) * 16 + (quad & 3) * 4);
-                                              *reinterpret_cast<float4*>(ou) = y0;
-                                              if (2 * tr + 1 < BX_ELE) *reinterpret_cast<float4*>(ou + BX_AZI * 16) = y1;
+                                              bx_st_stream(reinterpret_cast<float4*>(ou), y0);
+                                              if (2 * tr + 1 < BX_ELE) bx_st_stream(reinterpret_cast<float4*>(ou + BX_AZI * 16), y1);
                                           }
                                       });
         ug = ugn;
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(CT, 2) void wino_pose_kernel(const float* __restric
                                             const int tr = t / TT, tc = t - tr * TT;
                                             float* ou = out + ((((size_t)u * NT + (int)blockIdx.y * (CW / 16) + (quad >> 2)) * POUT +
                                                                 (2 * tr) * DO + 2 * tc + j) * 16 + (quad & 3) * 4);
-                                            *reinterpret_cast<float4*>(ou) = y0;
+                                            *reinterpret_cast<float4*>(ou) = y0;   // plain stores: the next CostNet layer finds the map in L2
                                             *reinterpret_cast<float4*>(ou + DO * 16) = y1;
                                         }
                                     });
