@@ -35,12 +35,14 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32
 PEAK_HBM_GBS = 8000.0            # HBM3E spec (6.29 TB/s measured achievable)
 DESC_CONV_MMAC_PER_PATCH = 3.871 + 5.161 + 10.322 + 20.644 + 10.322 + 5.161 + 2.580 + 1.290
-# what the shipped kernels issue on the matrix pipe for the Desc stack: layers 0..5 (>= 64 output channels) as Winograd F(2x2, 3x3)
-# -- 16 planes x 48 tile rows (40 used) per unit instead of 9 taps x 140 positions: 768 / 1260 of the direct MACs -- layers 6, 7 direct
-# (two units per workgroup: 16 planes x 40 tile rows, no padding: 640 / 1260 of the direct MACs)
-DESC_WINO_EXECUTED_MMAC_PER_PATCH = (3.871 + 5.161 + 10.322 + 20.644 + 10.322 + 5.161) * 640.0 / 1260.0 + 2.580 + 1.290
-# F(4x4, 3x3), the default since the end of round 3: 36 planes x 32 tile rows (30 used) per three units = 384 / 1260 of the direct MACs
-DESC_WINO43_EXECUTED_MMAC_PER_PATCH = (3.871 + 5.161 + 10.322 + 20.644 + 10.322 + 5.161) * 384.0 / 1260.0 + 2.580 + 1.290
+# what the kernels issue on the matrix pipe for the Desc stack, per form (bx_params.desc_conv_form):
+#  winograd43 (default, round 4: ALL eight layers): 36 planes x 32 tile rows (30 used) per three units = 384 / 1260 of the direct MACs
+#  winograd22: layers 0..5 (>= 64 output channels) 16 planes x 40 tile rows per two units = 640 / 1260, layers 6, 7 direct
+DESC_EXECUTED_MMAC_PER_PATCH = {
+    "winograd43": DESC_CONV_MMAC_PER_PATCH * 384.0 / 1260.0,
+    "winograd22": (3.871 + 5.161 + 10.322 + 20.644 + 10.322 + 5.161) * 640.0 / 1260.0 + 2.580 + 1.290,
+    "direct": DESC_CONV_MMAC_PER_PATCH,
+}
 COSTNET_MMAC_PER_MATCH = 80.0    # the reference's CostNet on the materialised 20-shift cost volume
 # what the shipped kernels execute: layer 0 collapsed to its P - Q form (k_cost.hip: 1.42 MMAC of binary64 VALU work instead of the
 # 26.87 MMAC fp32 convolution of the volume); the remaining 53.1 MMAC of layers 1..9 are f32 MFMA work
@@ -71,7 +73,7 @@ def profile_json(name, files=()):
         now = sha_map()
     except Exception:
         now = {}
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name))) as f:
                 d = json.load(f)
@@ -145,7 +147,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--inflight", type=int, default=8, help="pairs in flight per GPU (contexts / HIP streams)")
     ap.add_argument("--lane", type=int, default=0, help="bx_lane mode ordering the pairs in flight: 0 none, 1 whole main phase, 2 conv stacks")
-    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs (cycled; the same list on every rank)")
+    ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic pairs (cycled; the same list on every rank); N of every cloud is drawn from U[20k, 60k]")
+    ap.add_argument("--desc-conv", default=None, choices=["winograd43", "winograd22", "direct"], help="bx_params.desc_conv_form (default: the library default)")
+    ap.add_argument("--pose-conv", default=None, choices=["winograd", "direct"], help="bx_params.pose_conv_form")
+    ap.add_argument("--cost-l0", default=None, choices=["collapsed", "direct"], help="bx_params.cost_l0_form")
+    ap.add_argument("--inflight-sweep", default="1,2,4,8", help="pairs in flight of the throughput-vs-latency sweep after the timed region ('' = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e-pairs", type=int, default=24, help="pairs of the file-driven end-to-end measurement per RNG mode (0 = skip; N = 1 only)")
     ap.add_argument("--num-fps", type=int, default=5000)
@@ -193,6 +199,11 @@ def main():
         cfg.match.enable_early_exit = True      # config/outdoor_config.py:76 (the TIERS configs inherit it)
         cfg.match.early_exit_min_inliers = 50
     S, K, P = args.scales, args.num_fps, args.ppp
+    # arithmetic forms: explicit configuration (bx_params), echoed by every bx_result and checked in harvest() -- never the environment
+    for key, val in (("desc_conv", args.desc_conv), ("pose_conv", args.pose_conv), ("cost_l0", args.cost_l0)):
+        if val:
+            cfg.arith[key] = val
+    forms = bx.config.arith_of(cfg)
     pw = bx.weights.fold_and_pack(bx.weights.synthetic_state_dict(0))
 
     pairs = make_inputs(bx, args.distinct, 100, S, args.workload)
@@ -223,6 +234,8 @@ def main():
             r = results[c]
             if r.status != 0:       # device-side failure bits (e.g. the bounded spin of the multi-workgroup FPS timed out)
                 raise RuntimeError("pair %d: bx_result.status = 0x%x" % (gid, r.status))
+            if lib.forms_of_result(r) != forms:
+                raise RuntimeError("pair %d ran in %s, configured %s" % (gid, lib.forms_of_result(r), forms))
             pose = np.array(r.pose, np.float64).reshape(4, 4)
             if cfg.test.pose_refine is True:
                 pose = pose.astype(np.float32)
@@ -278,6 +291,17 @@ def main():
     # Latency at ONE pair in flight (service time of a pair; p50_ms_per_pair above is queueing latency at `inflight` pairs in flight)
     n1 = min(len(dpairs) * 2, 8)
     lat1, rec1 = run(n1, depth=1)
+    # throughput vs latency over the number of pairs in flight (short runs right after the timed region; the headline uses --inflight)
+    sweep = []
+    for d in [int(x) for x in args.inflight_sweep.split(",") if x.strip()]:
+        if d < 1 or d > C:
+            continue
+        nsw = max(2 * d, min(16, 4 * d))
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        lsw, _ = run(nsw, depth=d)
+        torch.cuda.synchronize()
+        sweep.append({"inflight": d, "pairs_per_s": round(nsw / (time.perf_counter() - ts), 3), "p50_ms": round(float(np.median(lsw)), 3), "pairs": nsw})
     # the same in the LATENCY FORM of the whole-pair call (bx_params.keypoint_tiles): FPS on the context's own stream in tiles,
     # the descriptors of a tile computed while the next one is sampled.  Same results bit for bit (checked here).
     lat1t, tiles_same = None, None
@@ -327,7 +351,7 @@ def main():
         # launches that did work: with the early exit taken the kernels of the later scales return at once (device-side skip
         # flag) but are still bracketed by events -- per-launch averages are taken over the scales that ran
         ran = mean_scales / S
-        CONV_SRC = ("k_conv.hip", "k_conv32.hip", "k_wino.hip", "k_wino43.hip", "bx_common.h")
+        CONV_SRC = ("k_conv.hip", "k_wino.hip", "k_wino43.hip", "bx_common.h")
         pmc = profile_json("pmc_traffic", CONV_SRC)
         pmc_ball = profile_json("pmc_traffic", ("k_ball.hip", "bx_common.h"))
         busy = profile_json("mfma_busy", CONV_SRC)
@@ -341,35 +365,35 @@ def main():
         if conv_n:
             conv_n = max(1, int(round(conv_n * ran)))
             ach = flops_per_stack / (conv_ms / conv_n * 1e-3) / 1e12
-            form = os.environ.get("BX_DESC_CONV", "winograd43")
-            wino = form != "direct"
-            w43 = form not in ("direct", "winograd")
-            ex_mmac = DESC_WINO43_EXECUTED_MMAC_PER_PATCH if w43 else (DESC_WINO_EXECUTED_MMAC_PER_PATCH if wino else DESC_CONV_MMAC_PER_PATCH)
+            form = forms["desc_conv"]
+            ex_mmac = DESC_EXECUTED_MMAC_PER_PATCH[form]
             ex_ach = 2.0 * ex_mmac * 1e6 * K / (conv_ms / conv_n * 1e-3) / 1e12
-            roof = {"kernel": ("wino43_kernel<...> x6 (Winograd F(4x4,3x3), three units per workgroup) + conv_kernel<...> x2" if w43 else
-                               "wino_pair_kernel<...> x6 (Winograd F(2x2,3x3), two units per workgroup) + conv_kernel<...> x2" if wino else "conv_kernel<...> x8") + " (Cylindrical_Net stack, f32 MFMA)",
+            roof = {"kernel": {"winograd43": "wino43_kernel<...> x8 (Winograd F(4x4,3x3), three units per workgroup; every layer)",
+                               "winograd22": "wino_pair_kernel<...> x6 (Winograd F(2x2,3x3), two units per workgroup) + conv_kernel<...> x2",
+                               "direct": "conv_kernel<...> x8"}[form] + " (Cylindrical_Net stack, f32 MFMA)",
                     "bound": "mfma",
-                    "achieved": round(ach, 3), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MATRIX_TFLOPS, 4),
-                    "frac_note": "ALGORITHMIC flops of the layers (59.35 MMAC per patch, SURVEY.md App. B: what the reference's cuDNN convolution "
-                                 "multiplies) over the measured time" + (("; the Winograd layers issue %s / 1260 of those multiplications, so this figure "
-                                 "is an algorithm-adjusted rate, not matrix-pipe utilisation: see executed_*") % ("384" if w43 else "640") if wino else ""),
-                    "executed_flops_per_launch": 2.0 * ex_mmac * 1e6 * K, "executed_achieved": round(ex_ach, 3),
-                    "executed_frac": round(ex_ach / PEAK_F32_MATRIX_TFLOPS, 4),
+                    # the roofline statement: flops ISSUED on the matrix pipe / time / peak (<= 1 by construction)
+                    "achieved": round(ex_ach, 3), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ex_ach / PEAK_F32_MATRIX_TFLOPS, 4),
+                    "executed_flops_per_launch": 2.0 * ex_mmac * 1e6 * K,
+                    # the algorithm-adjusted rate: what the reference's convolution multiplies (59.35 MMAC per patch) over
+                    # the same time; exceeds the peak when a Winograd form issues fewer multiplications -- NOT a roofline fraction
+                    "algorithmic_flops_per_launch": flops_per_stack, "algorithmic_rate_tflops": round(ach, 3),
+                    "algorithmic_rate_x_peak": round(ach / PEAK_F32_MATRIX_TFLOPS, 4),
+                    "issued_over_direct_macs": round(ex_mmac / DESC_CONV_MMAC_PER_PATCH, 4),
                     "traffic": pmc["desc_conv_stack_bytes_per_launch"] if fresh(pmc) else None,
                     "traffic_note": "HBM bytes per stack launch, rocprofv3 PMC: %s; algorithmic in+out maps = 3.27e9" % stale_note(pmc),
                     "mfma_busy": busy.get("desc_conv_stack") if fresh(busy) else None,
                     "mfma_busy_note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), time-weighted over the 8 layers: %s" % stale_note(busy),
                     "avg_launch_ms": round(conv_ms / conv_n, 4), "launches": conv_n,
-                    "algorithmic_flops_per_launch": flops_per_stack,
                     "note": "hipEvent-timed on the kernels' stream, one pair in flight, %d pairs right after the timed region" % NPROF}
         # --- CostNet (cost_l1_kernel + 9 conv_kernel launches + soft-argmax per scale); m = matches of the profiled pairs
         pose_ms, pose_n = stages.get("pose_net", (0.0, 0))
         roof_cn = None
         if pose_n:
             pose_n = max(1, int(round(pose_n * ran)))
-            direct0 = os.environ.get("BX_COST_L0") == "direct"
-            wino_p = os.environ.get("BX_POSE_CONV", "winograd") != "direct"
+            direct0 = forms["cost_l0"] == "direct"
+            wino_p = forms["pose_conv"] != "direct"
             # algorithmic work of layers 1..9 as the reference's convolutions run them (53.12 MMAC per match) + layer 0: 26.87 MMAC on the
             # materialised cost volume, or the 1.42 MMAC that remain of it after the algebraic collapse (k_cost.hip)
             alg = COSTNET_MMAC_PER_MATCH if direct0 else COSTNET_MMAC_PER_MATCH - COSTNET_L0_MMAC + COSTNET_L0_COLLAPSED_MMAC
@@ -381,14 +405,14 @@ def main():
             ex_ach = 2.0 * ex * 1e6 * mean_m / (pose_ms / pose_n * 1e-3) / 1e12
             roof_cn = {"kernel": ("cost_l1_kernel" if direct0 else "cost_l0_kernel (collapsed layer 0, binary64 VALU)") +
                                  (" + wino_pose_kernel x5 (Winograd F(2x2,3x3)) + conv_kernel x4" if wino_p else " + conv_kernel x9") + " + soft_argmax (CostNet)",
-                       "bound": "mfma", "achieved": round(ach, 3),
-                       "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MATRIX_TFLOPS, 4),
-                       "flops_note": "ALGORITHMIC flops (%.2f MMAC per match: layers 1..9 as direct convolutions + layer 0 %s) over the time of the "
-                                     "whole CostNet; the reference's own arithmetic (80.0 MMAC per match on the materialised cost volume) in the same "
-                                     "time = %.1f TFLOP/s; executed_* = flops issued on the f32 matrix pipe (%.2f MMAC per match)"
+                       "bound": "mfma", "achieved": round(ex_ach, 3),
+                       "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": round(ex_ach / PEAK_F32_MATRIX_TFLOPS, 4),
+                       "frac_note": "flops ISSUED on the f32 matrix pipe (%.2f MMAC per match) over the time of the whole CostNet / peak" % ex,
+                       "algorithmic_rate_tflops": round(ach, 3), "algorithmic_rate_x_peak": round(ach / PEAK_F32_MATRIX_TFLOPS, 4),
+                       "flops_note": "algorithmic_* = %.2f MMAC per match (layers 1..9 as direct convolutions + layer 0 %s) over the same time; the "
+                                     "reference's own arithmetic (80.0 MMAC per match on the materialised cost volume) in that time = %.1f TFLOP/s"
                                      % (alg, "on the materialised volume" if direct0 else "after its algebraic collapse: 1.42 MMAC",
-                                        2.0 * COSTNET_MMAC_PER_MATCH * 1e6 * mean_m / (pose_ms / pose_n * 1e-3) / 1e12, ex),
-                       "executed_achieved": round(ex_ach, 3), "executed_frac": round(ex_ach / PEAK_F32_MATRIX_TFLOPS, 4),
+                                        2.0 * COSTNET_MMAC_PER_MATCH * 1e6 * mean_m / (pose_ms / pose_n * 1e-3) / 1e12),
                        "traffic": None, "mfma_busy": busy_cn.get("costnet") if fresh(busy_cn) else None,
                        "avg_launch_ms": round(pose_ms / pose_n, 4), "launches": pose_n,
                        "algorithmic_flops_per_launch": fl, "mean_matches_per_launch": round(mean_m, 1)}
@@ -417,8 +441,12 @@ def main():
         out = {
             "metric": "registered pairs/sec + p50 ms/pair, 3DMatch 5k-FPS 3-scale, 1/2/4/8 MI355X",
             "value": round(value, 4), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "p50_ms_per_pair": round(float(np.median(lat)), 3),
-            "p50_ms_per_pair_inflight1": round(float(np.median(lat1)), 3),
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            # p50 ms/pair of the metric = SERVICE time of a pair (one in flight, throughput form); the latency seen inside the timed region
+            # (queueing behind the other pairs in flight) is listed under its own key
+            "p50_ms_per_pair": round(float(np.median(lat1)), 3),
+            "p50_ms_per_pair_queueing_at_inflight": {"inflight": C, "p50_ms": round(float(np.median(lat)), 3)},
+            "inflight_sweep": sweep,
             "p50_ms_per_pair_latency_form": None if lat1t is None else {
                 "p50_ms": round(float(np.median(lat1t)), 3), "keypoint_tiles": args.latency_tiles, "pairs_in_flight": 1,
                 "results_identical_to_throughput_form": tiles_same,
@@ -426,7 +454,7 @@ def main():
                         "beside the sampling of the next"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl_text % (S, K, P),
-                       "pairs_in_flight_per_gpu": C, "parallelism": "pair-sharded x%d, one all-gather of %d B float64 records" % (world, 8 * D.RECORD),
+                       "pairs_in_flight_per_gpu": C, "arithmetic_forms": forms, "distinct_pairs": len(pairs), "parallelism": "pair-sharded x%d, one all-gather of %d B float64 records" % (world, 8 * D.RECORD),
                        "weights": "seeded random (reference snapshot layout)", "mean_points_per_cloud": nmean,
                        "workload_generator": "synth.make_pair v2 (round 2+: shared=True noise-free partial-overlap fragments; round 1 used "
                                              "independently sampled jittered fragments = --workload 3dmatch-noisy; rates of the two are not comparable)"},
@@ -460,33 +488,43 @@ def main():
         sp = split_precision_note()
         if sp:
             out["experiments"] = {"split_precision": sp}
-            if sp["active_in_this_run"]:       # a line under the experiment's switch is not a line of the product
-                out["dtype"] = "f32 + bf16x3 split-precision layer (EXPERIMENT, not the shipped arithmetic)"
-                out["config"]["experiment"] = "BX_EXP_SPLIT_CONV=1"
+        ref = reference_forward_note()
+        if ref:
+            out["cpu_baseline_reference"] = ref
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
 def split_precision_note():
-    """Pointer to the MEASUREMENT of a split-precision convolution (profiles/r03_split_precision.json; never part of `value`, `dtype`
-    or the roofline objects: the shipped path is exact f32).  None when the environment switch of the experiment is set -- a line
-    produced under BX_EXP_SPLIT_CONV=1 is not a benchmark line of the product and says so in config."""
+    """Pointer to the round-3 MEASUREMENT of a split-precision convolution (profiles/r03_split_precision.json); its kernel is not part
+    of the library any more (tools/experimental/k_split.hip) and never was part of `value`, `dtype` or the roofline objects."""
     try:
         with open(os.path.join(ROOT, "profiles", "r03_split_precision.json")) as f:
             d = json.load(f)
         e = d["layer_error_vs_binary64"]
-        return {"file": "profiles/r03_split_precision.json", "shipped": False,
+        return {"file": "profiles/r03_split_precision.json", "shipped": False, "in_library": False,
                 "what": "Cylindrical_Net layer 3 (128 -> 128) with 3 x bf16 pieces per fp32 operand, 6 partial products, fp32 accumulation "
-                        "(v_mfma_f32_16x16x32_bf16), measured against the exact f32 kernels; BX_EXP_SPLIT_CONV=1",
+                        "(v_mfma_f32_16x16x32_bf16), measured in round 3 against the exact f32 kernels",
                 "max_abs_error_vs_binary64": {k: e[k]["max_abs"] for k in ("direct_f32", "winograd_f32", "split_bf16x3")},
-                "descriptor_max_abs_delta": d["descriptor_delta_vs_shipped"]["desc_max_abs_delta"],
-                "fixtures_counts_identical_to_reference": all(r["counts_split"] == r["counts_reference"] for r in d["reference_minted_fixtures"]),
-                "fixtures_max_pose_delta_vs_exact_deg_m": [max(r["pose_vs_exact_deg_m"][i] for r in d["reference_minted_fixtures"]) for i in (0, 1)],
-                "kernel_us_per_launch": d["kernel_time_us_per_launch_K5000"],
-                "active_in_this_run": bool(int(os.environ.get("BX_EXP_SPLIT_CONV", "0") or 0))}
+                "kernel_us_per_launch": d["kernel_time_us_per_launch_K5000"]}
     except Exception:
         return None
+
+
+def reference_forward_note():
+    """The reference's OWN BufferX.forward (models/BUFFERX.py:257-467, unmodified, un-vendored CUDA ops as numpy stand-ins) timed on
+    BASELINE configs[0] in the build container by tools/time_reference.py (it needs /root/reference, which the GPU box does not have):
+    read from profiles/, never measured here."""
+    for rnd in ("r04",):
+        try:
+            with open(os.path.join(ROOT, "profiles", "%s_cpu_reference.json" % rnd)) as f:
+                d = json.load(f)
+            d["file"] = "profiles/%s_cpu_reference.json" % rnd
+            return d
+        except Exception:
+            continue
+    return None
 
 
 def e2e_rate(bx, pw, cfg, args, device, hot_value):

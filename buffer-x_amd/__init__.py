@@ -4,6 +4,6 @@ Layout: csrc/ (HIP kernels + C-ABI, built into csrc/libbufferx_hip.so), lib.py (
 model.py (drop-in `BufferX` mirroring reference models/BUFFERX.py), weights.py, config.py, synth.py.
 """
 from .config import make_cfg, Cfg  # noqa: F401
-from . import weights, synth  # noqa: F401
+from . import config, weights, synth  # noqa: F401
 
-__all__ = ["make_cfg", "Cfg", "weights", "synth"]
+__all__ = ["make_cfg", "Cfg", "config", "weights", "synth"]

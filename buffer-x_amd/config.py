@@ -28,8 +28,28 @@ class Cfg(dict):
             raise AttributeError(k)
 
 
+# Arithmetic forms of the three stages that have more than one (include/bufferx.h bx_params.desc_conv_form / pose_conv_form /
+# cost_l0_form; no reference counterpart: the reference leaves the summation order of its convolutions to cuDNN / ATen).  Index in the
+# tuple = the C-ABI value; the first entry of each is the default.  cfg.arith carries the names; the oracle takes the same names.
+ARITH_FORMS = {"desc_conv": ("winograd43", "winograd22", "direct"), "pose_conv": ("winograd", "direct"), "cost_l0": ("collapsed", "direct")}
+# what make_cfg puts into cfg.arith.  tests/conftest.py --arith overrides it for a whole test run (every form is covered that way);
+# nothing reads the process environment.
+ARITH_DEFAULT = {k: v[0] for k, v in ARITH_FORMS.items()}
+
+
+def arith_of(cfg):
+    """The validated arithmetic forms of a knob tree (missing keys = defaults)."""
+    ar = dict(ARITH_DEFAULT)
+    ar.update(dict(cfg.get("arith", {}) or {}))
+    for k, v in ar.items():
+        if k not in ARITH_FORMS or v not in ARITH_FORMS[k]:
+            raise ValueError(f"unknown arithmetic form {k}={v!r} (known: {ARITH_FORMS})")
+    return ar
+
+
 def _base(indoor):
     c = Cfg()
+    c.arith = dict(ARITH_DEFAULT)
     c.stage = "test"
     c.data = dict(dataset="", voxel_size_0=0.035 if indoor else 0.30)
     c.test = dict(pose_refine=False, enable_timing=False,

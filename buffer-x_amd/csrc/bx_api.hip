@@ -294,7 +294,7 @@ __global__ void pose_to_float_kernel(PairState* st)
     if (threadIdx.x < 16) st->Tf[threadIdx.x] = (float)st->T[threadIdx.x];
 }
 
-__global__ void finalize_kernel(const PairState* st, const int32_t* err, int refine, int nscales, bx_result* out)
+__global__ void finalize_kernel(const PairState* st, const int32_t* err, int refine, int nscales, int forms, bx_result* out)
 {
     if (threadIdx.x == 0) {
         for (int i = 0; i < 16; ++i) out->pose[i] = refine ? (double)st->Tf[i] : st->T[i];
@@ -305,7 +305,7 @@ __global__ void finalize_kernel(const PairState* st, const int32_t* err, int ref
         out->ransac_iters = st->ransac_iters;
         out->refine_iters = st->refine_iters;
         out->status = err[0];
-        out->reserved = 0;
+        out->arith_forms = forms;
         for (int i = 0; i < BX_MAX_SCALES; ++i) out->des_r[i] = i < nscales ? (float)st->des_r[i] : 0.0f;
     }
 }
@@ -384,22 +384,10 @@ static int create_impl(bx_ctx* c, int device_id)
         c->conv_persist = (!e || atoi(e) != 0) ? 1 : 0;
         e = getenv("BX_CONV_PERSIST_CAP");
         c->conv_cap_override = e ? atoi(e) : 0;
-        // BX_CONV32=1: Cylindrical_Net layers 0-5 on the 32x32x2 loader/compute kernels of k_conv32.hip instead of the 16x16x4
-        // kernels of k_conv.hip.  Bit-identical results; measured layer by layer within +-2 % of each other (both sit
-        // at ~90 % matrix-pipe occupancy and the chip lowers its clock as the occupancy rises), the 16x16x4 form is the default.
-        e = getenv("BX_CONV32");
-        c->use_conv32 = (e && atoi(e) != 0) ? 1 : 0;
-        // Cylindrical_Net layers with >= 64 output channels: Winograd F(2x2, 3x3) (k_wino.hip, the default: 0.61x the MFMA work of the
-        // direct form) or BX_DESC_CONV=direct (conv_kernel of k_conv.hip).  The two forms have different arithmetic contracts
-        // (oracle: bxo_conv_wino / bxo_conv); oracle/oracle.py follows the same variable.
-        e = getenv("BX_DESC_CONV");
-        c->use_wino = (e && strcmp(e, "direct") == 0) ? 0 : ((e && strcmp(e, "winograd") == 0) ? 1 : 2);   // default: winograd43
-        e = getenv("BX_POSE_CONV");
-        c->use_wino_pose = (e && strcmp(e, "direct") == 0) ? 0 : 1;
-        e = getenv("BX_EXP_SPLIT_CONV");
-        c->exp_split = (e && atoi(e) != 0) ? 1 : 0;
-        e = getenv("BX_COST_L0");
-        c->cost_direct = (e && strcmp(e, "direct") == 0) ? 1 : 0;
+        // arithmetic forms: bx_params (validated by bx_create), never the environment
+        c->use_wino = p.desc_conv_form == BX_DESC_CONV_DIRECT ? 0 : (p.desc_conv_form == BX_DESC_CONV_WINOGRAD22 ? 1 : 2);
+        c->use_wino_pose = p.pose_conv_form == BX_POSE_CONV_DIRECT ? 0 : 1;
+        c->cost_direct = p.cost_l0_form == BX_COST_L0_DIRECT ? 1 : 0;
     }
     (void)p;
     c->prof = new std::vector<ProfEvt>();
@@ -468,6 +456,12 @@ int bx_create(int device_id, const bx_params* params, bx_ctx** out)
         bx_set_error("bx_create: invalid parameters");
         return BX_ERR_ARG;
     }
+    if (p.desc_conv_form < 0 || p.desc_conv_form > BX_DESC_CONV_DIRECT || p.pose_conv_form < 0 || p.pose_conv_form > BX_POSE_CONV_DIRECT ||
+        p.cost_l0_form < 0 || p.cost_l0_form > BX_COST_L0_DIRECT) {
+        bx_set_error("bx_create: unknown arithmetic form (desc_conv_form %d, pose_conv_form %d, cost_l0_form %d)", p.desc_conv_form,
+                     p.pose_conv_form, p.cost_l0_form);
+        return BX_ERR_ARG;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) {
         bx_set_error("bx_create: device %d not available (%d devices)", device_id, ndev);
@@ -519,7 +513,7 @@ int bx_destroy(bx_ctx* c)
     (void)hipFree(c->d_cost_wp); (void)hipFree(c->d_cost_wq);
     (void)hipFree(c->d_centres); (void)hipFree(c->d_rot); (void)hipFree(c->d_rowc); (void)hipFree(c->d_rad_thr);
     (void)hipFree(c->d_pnt_w); (void)hipFree(c->d_pnt_b); (void)hipFree(c->d_pool_w1); (void)hipFree(c->d_pool_b1); (void)hipFree(c->d_pool_w2); (void)hipFree(c->d_pool_b2);
-    for (int i = 0; i < BX_NDESC; ++i) { (void)hipFree(c->desc[i].W); (void)hipFree(c->desc[i].W32); (void)hipFree(c->desc[i].Wwino); (void)hipFree(c->desc[i].Wwino43); (void)hipFree(c->desc[i].Wsplit); (void)hipFree(c->desc[i].b); (void)hipFree(c->desc[i].lrow); (void)hipFree(c->desc[i].lrow2); (void)hipFree(c->desc[i].obase); (void)hipFree(c->desc[i].toff); }
+    for (int i = 0; i < BX_NDESC; ++i) { (void)hipFree(c->desc[i].W); (void)hipFree(c->desc[i].Wwino); (void)hipFree(c->desc[i].Wwino43); (void)hipFree(c->desc[i].b); (void)hipFree(c->desc[i].lrow); (void)hipFree(c->desc[i].lrow2); (void)hipFree(c->desc[i].obase); (void)hipFree(c->desc[i].toff); }
     for (int i = 0; i < BX_NPOSE; ++i) { (void)hipFree(c->pose[i].W); (void)hipFree(c->pose[i].Wwino); (void)hipFree(c->pose[i].b); (void)hipFree(c->pose[i].lrow); (void)hipFree(c->pose[i].lrow2); (void)hipFree(c->pose[i].obase); (void)hipFree(c->pose[i].toff); }
     delete c;
     return BX_OK;
@@ -617,17 +611,6 @@ int bx_load_weights(bx_ctx* c, const bx_weights* w)
                         }
         return upload(&L.W, wp.data(), wp.size());
     };
-    // 32x32x2 form: element j of lane (kk = lane >> 5, n = lane & 31) = W[chunk][tap][2 j + kk][tile*32 + n]
-    auto upload_w32 = [&](ConvLayerDev& L, const float* wsrc) -> int {
-        const int nct = L.nchunk * L.ntaps, nt = L.cout / 32;
-        std::vector<float> wp((size_t)nct * nt * 64 * 8, 0.0f);
-        for (int ct = 0; ct < nct; ++ct)
-            for (int t = 0; t < nt; ++t)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 8; ++j)
-                        wp[(((size_t)ct * nt + t) * 64 + lane) * 8 + j] = wsrc[((size_t)ct * 16 + 2 * j + (lane >> 5)) * L.cout + t * 32 + (lane & 31)];
-        return upload(&L.W32, wp.data(), wp.size());
-    };
     const ConvGeo cg = cyl_geo();
     auto upload_geo = [&](ConvLayerDev& L, const ConvGeo& g) -> int {
         int r;
@@ -641,10 +624,8 @@ int bx_load_weights(bx_ctx* c, const bx_weights* w)
         ConvLayerDev& L = c->desc[l];
         L.nchunk = dc[l][0]; L.ntaps = 9; L.p_in = BX_EA; L.p_out = BX_EA; L.cout = dc[l][1]; L.relu = l < BX_NDESC - 1;
         if ((rc = upload_w(L, w->desc_w[l])) != BX_OK) return rc;
-        if ((rc = upload_w32(L, w->desc_w[l])) != BX_OK) return rc;
-        if ((rc = bxk_wino_weights(w->desc_w[l], L.nchunk, 1, L.cout, &L.Wwino)) != BX_OK) return rc;
-        if (c->use_wino == 2 && L.cout >= 64 && (rc = bxk_wino43_weights(w->desc_w[l], L.nchunk, L.cout, &L.Wwino43)) != BX_OK) return rc;
-        if (l == 3 && c->exp_split && (rc = bxk_split_weights(w->desc_w[l], L.nchunk, L.cout, &L.Wsplit)) != BX_OK) return rc;
+        if (c->use_wino == 1 && L.cout >= 64 && (rc = bxk_wino_weights(w->desc_w[l], L.nchunk, 1, L.cout, &L.Wwino)) != BX_OK) return rc;
+        if (c->use_wino == 2 && (rc = bxk_wino43_weights(w->desc_w[l], L.nchunk, L.cout, &L.Wwino43)) != BX_OK) return rc;
         if ((rc = upload(&L.b, w->desc_b[l], (size_t)L.cout)) != BX_OK) return rc;
         if ((rc = upload_geo(L, cg)) != BX_OK) return rc;
     }
@@ -662,7 +643,7 @@ int bx_load_weights(bx_ctx* c, const bx_weights* w)
         if ((rc = upload_w(L, w->pose_w[l])) != BX_OK) return rc;
         if ((rc = upload(&L.b, w->pose_b[l], (size_t)L.cout)) != BX_OK) return rc;
         if ((rc = upload_geo(L, vg)) != BX_OK) return rc;
-        if (l >= 1 && l <= 5 && (rc = bxk_wino_weights(w->pose_w[l], L.nchunk, k[1], L.cout, &L.Wwino)) != BX_OK) return rc;
+        if (c->use_wino_pose && l >= 1 && l <= 5 && (rc = bxk_wino_weights(w->pose_w[l], L.nchunk, k[1], L.cout, &L.Wwino)) != BX_OK) return rc;
         for (int i = 0; i < 3; ++i) dims[i] = o[i];
     }
     if ((rc = bxk_cost_l0_weights(w->pose_w[0], &c->d_cost_wp, &c->d_cost_wq)) != BX_OK) return rc;
@@ -1060,7 +1041,8 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
         hipLaunchKernelGGL(pose_to_float_kernel, dim3(1), dim3(64), 0, s, st);
         { ProfScope ps(c, s, 10); if ((rc = bxk_refine(c, s, c->ss_cat, c->tt_cat, &st->M, S * K, st->Tf, &st->refine_iters)) != BX_OK) return rc; }
     }
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, s, st, c->err_flag, p.pose_refine, S, c->result_dev);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, s, st, c->err_flag, p.pose_refine, S,
+                       p.desc_conv_form | (p.pose_conv_form << 8) | (p.cost_l0_form << 16), c->result_dev);
     BX_LAUNCH_CHECK();
     BX_HIP(hipMemcpyAsync(result, c->result_dev, sizeof(bx_result), hipMemcpyDeviceToHost, s));
     return BX_OK;

@@ -43,10 +43,8 @@ constexpr int BX_NDESC = 8, BX_NPOSE = 10;
 
 struct ConvLayerDev {
     float* W;        // B fragments of the 16x16x4 kernels: [chunk*taps][column tile 16][lane][4]
-    float* W32;      // B fragments of the 32x32x2 kernels (k_conv32.hip): [chunk*taps][column tile 32][lane][8]; Desc layers only
     float* Wwino;    // B fragments of the Winograd kernels (k_wino.hip): U = G g G^T, [chunk*16 + plane][column tile 16][lane][4]; Desc layers only
-    float* Wwino43;  // B fragments of the F(4x4, 3x3) kernels (k_wino43.hip): [chunk*36 + plane][column tile 16][lane][4]; BX_DESC_CONV=winograd43
-    void* Wsplit;    // EXPERIMENT (BX_EXP_SPLIT_CONV=1, k_split.hip): bf16 piece fragments of Desc layer 3, else null
+    float* Wwino43;  // MFMA fragments of the F(4x4, 3x3) kernels (k_wino43.hip): [chunk*36 + plane][column tile 16][lane][4], columns in output-slot order; desc_conv_form winograd43
     float* b;        // [cout]
     int32_t* lrow;   // [p_in]  LDS row of an input position inside a unit's p_lds-row slab
     int32_t* lrow2;  // [p_in]  second copy (azimuth wrap halo) or -1
@@ -182,15 +180,13 @@ struct bx_ctx {
     int kiss_max_C;
     void* pre;                          // bx_pre_ws* (k_pre.hip): workspace of the pre-processing entry points, reserved on demand
     int conv_cap[2][BX_NPOSE];          // persistent-grid size of every conv layer on THIS device (0 = not set up yet)
-    int conv32_cap[BX_NDESC];           // the same for the 32x32x2 kernels (k_conv32.hip)
     int wino_cap[BX_NDESC];             // the same for the Winograd kernels (k_wino.hip)
     int wino_pose_cap[BX_NPOSE];
-    int use_wino_pose;                  // BX_POSE_CONV != direct: CostNet layers 1..5 as valid Winograd convolutions
-    int exp_split;                      // BX_EXP_SPLIT_CONV=1: measurement-only split-precision form of Desc layer 3 (k_split.hip)
-    int use_wino;                       // BX_DESC_CONV: 1 = winograd (F(2x2, 3x3)), 2 = winograd43 (F(4x4, 3x3)), 0 = direct;: Cylindrical_Net layers as F(2x2, 3x3) Winograd convolutions
-    int conv_persist, conv_cap_override, n_cu, use_conv32;
+    int use_wino_pose;                  // bx_params.pose_conv_form == winograd: CostNet layers 1..5 as valid Winograd convolutions
+    int use_wino;                       // bx_params.desc_conv_form: 2 = winograd43 (F(4x4, 3x3), every layer), 1 = winograd22 (F(2x2, 3x3), layers with >= 64 output channels), 0 = direct
+    int conv_persist, conv_cap_override, n_cu;
     double *d_cost_wp, *d_cost_wq;      // collapsed CostNet layer 0 (k_cost.hip): binary64 weights of the P / Q convolutions
-    int cost_direct;                    // BX_COST_L0=direct: layer 0 as the fp32 MFMA convolution of the implicit volume (cost_l1_kernel)
+    int cost_direct;                    // bx_params.cost_l0_form == direct: layer 0 as the fp32 MFMA convolution of the implicit volume (cost_l1_kernel)
     int32_t* conv_ctr;                  // [2 * BX_NDESC] {next group ticket, departed workgroups} of the 32x32x2 kernels' group walk
     bx_capture cap;                     // bx_set_capture: intermediates of one scale copied to caller buffers
     int cap_on;
@@ -224,11 +220,8 @@ int bxk_patch_features(bx_ctx* c, hipStream_t s, const float* patches, int K, in
                        float* R_out, float* feat_out);
 int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, const int32_t* units_dev, int max_units,
              float* out);
-int bxk_conv32(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t* units_dev, int max_units, float* out);
 int bxk_wino43_weights(const float* w, int nchunk, int cout, float** d_out);
 int bxk_wino43(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t* units_dev, int max_units, float* out);
-int bxk_split_weights(const float* w, int nchunk, int cout, void** d_out);
-int bxk_split_conv(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t* units_dev, int max_units, float* out);
 int bxk_wino(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t* units_dev, int max_units, float* out);
 int bxk_wino_weights(const float* w, int nchunk, int fold, int cout, float** d_out);
 int bxk_wino_pose(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t* units_dev, int max_units, float* out);

@@ -558,21 +558,10 @@ int launch_conv(bx_ctx* c, int net, int layer, hipStream_t s, const ConvLayerDev
 int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, const int32_t* units_dev, int max_units, float* out)
 {
     constexpr int CYL = (BX_ELE + 2) * (BX_AZI + 2);   // 198 LDS rows per unit: cylindrical map + halo
-    if (net == 0 && c->exp_split) {
-        const int rcs = bxk_split_conv(c, s, layer, in, units_dev, max_units, out);   // measurement only (k_split.hip)
-        if (rcs >= 0) return rcs;
-    }
-    if (net == 0 && c->use_wino == 2) {
-        const int rc43 = bxk_wino43(c, s, layer, in, units_dev, max_units, out);
-        if (rc43 >= 0) return rc43;
-    }
-    if (net == 0 && c->use_wino) {
-        const int rcw = bxk_wino(c, s, layer, in, units_dev, max_units, out);
+    if (net == 0 && c->use_wino == 2) return bxk_wino43(c, s, layer, in, units_dev, max_units, out);      // F(4x4, 3x3): every layer
+    if (net == 0 && c->use_wino == 1) {
+        const int rcw = bxk_wino(c, s, layer, in, units_dev, max_units, out);                             // F(2x2, 3x3): layers 0..5
         if (rcw >= 0) return rcw;
-    }
-    if (net == 0 && c->use_conv32) {
-        const int rc32 = bxk_conv32(c, s, layer, in, units_dev, max_units, out);
-        if (rc32 >= 0) return rc32;
     }
     if (net == 0) {
         const ConvLayerDev& L = c->desc[layer];

@@ -8,24 +8,15 @@
 // folds the sixteen results back into the 2 x 2 outputs.  U = G g G^T is computed on the host in binary64 and rounded once.
 // The arithmetic contract is restated by oracle/bx_oracle.c::bxo_conv_wino; GPU == oracle bit for bit.
 //
-// Workgroup = 8 waves, 64 output channels of ONE unit (patch) at a time: wave (ct, half) owns the column tile ct (16 channels) and
-// the EIGHT planes of rows xi = 2 half, 2 half + 1, for all three 16-row tiles of the 48 (40 used) tile rows: 24 accumulator tiles =
-// 96 VGPRs at two waves per SIMD (256 VGPRs each: room for deep operand prefetch).  The 128-channel layers run two workgroups per
-// unit (blockIdx.y = channel half; both transform the unit's input); the two 32-channel layers stay on the direct kernels.
-// Persistent walk over the units.  Pipeline (ONE barrier per 16-channel chunk): chunks are numbered g = 0, 1, ... across the units of
-// the walk; V(g) lives in plane set g & 1, the slab of chunk g (input with its halo: 10 x 22 rows of 80 B) in slab buffer g & 1.
-// Iteration g: write the slab of chunk g + 2 (fetched one iteration earlier), request chunk g + 3, then -- one wave of every SIMD in
-// one order, the other in the other -- the input transform of chunk g + 1 (thread item = (xi, tile, 4-channel quad): four V planes)
-// and the MFMAs of chunk g (one ds_read_b128 feeds four MFMAs; the B fragment of a plane, one 16-byte load per lane requested a
-// whole chunk ahead, is reused by the three row tiles): while one wave streams MFMAs the other does the transform's VALU / LDS work.
-// Output transform (wino_output): every wave folds its two rows into r_xi[j] = (M0 + M1) + M2 | (M1 - M2) - M3 lane-locally and hands
-// its two quantities -- half 0: r0 + r1 and r1, half 1: r2 and r3 -- to an LDS exchange (bytes of the consumed plane set) that all
-// threads then read in output order: Y[0][j] = ((r0 + r1) + r2), Y[1][j] = ((r1 - r2) - r3), + bias, ReLU, 16-byte stores.
-// By default the layers run wino_pair_kernel below (two units per workgroup: no padding rows, single-buffered); this kernel is the
-// BX_WINO_PAIR=0 form.
-// Measured and not kept: one fat wave per SIMD, the slab write moved behind the transform (3-5 % slower),
-// -fno-slp-vectorize (no change).
-// MFMA work per unit and layer: 16 planes x 3 row tiles against 9 taps x 8.75 row tiles of the direct form (0.61x).
+// Two kernels: wino_pair_kernel (Cylindrical_Net layers with >= 64 output channels under bx_params.desc_conv_form = winograd22: two units
+// per workgroup, 2 x 40 tiles = five full MFMA row tiles, single-buffered slab + V planes, serialised phases) and wino_pose_kernel
+// (CostNet layers 1..5 as VALID F(2x2, 3x3) convolutions, the default pose_conv_form).  Wave (ct, half) owns the column tile ct and the
+// eight planes of rows xi = 2 half, 2 half + 1.  Output transform (wino_output): every wave folds its two rows into
+// r_xi[j] = (M0 + M1) + M2 | (M1 - M2) - M3 lane-locally and hands its two quantities -- half 0: r0 + r1 and r1, half 1: r2 and r3 --
+// to an LDS exchange (bytes of the consumed plane set) that all threads then read in output order: Y[0][j] = ((r0 + r1) + r2),
+// Y[1][j] = ((r1 - r2) - r3), + bias, ReLU, 16-byte stores.  The round-3 one-unit pipelined kernel (transform of one wave beside the
+// MFMAs of its SIMD sibling: 8 100 cycles per unit and chunk against 7 170 serialised) was removed in round 4; DESIGN.md section 2 keeps
+// its measurements.
 #include "bx_common.h"
 #include <cstdlib>
 #include <vector>
@@ -100,212 +91,6 @@ __device__ __forceinline__ void wino_output(const f32x4 (&acc)[8][RT], float* ex
     }
 }
 
-template <int NCHUNK, int COUT, bool RELU>
-__global__ __launch_bounds__(CT, 2) void wino_kernel(const float* __restrict__ in, int units, const float* __restrict__ U,
-                                                     const float* __restrict__ bias, float* __restrict__ out,
-                                                     const int32_t* __restrict__ skip)
-{
-    if (skip && *skip) return;
-    constexpr int NT = COUT / 16;
-    constexpr int NPIECE = BX_EA * 4;                          // float4 pieces of one chunk of one unit
-    constexpr int NLD = (NPIECE + CT - 1) / CT;
-    constexpr int NITEM = 4 * NT_ * 4, NIT = (NITEM + CT - 1) / CT;   // transform items (xi, tile, quad) per thread
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* slab0 = reinterpret_cast<float*>(smem);
-    float* V0 = slab0 + 2 * SLAB_FLOATS;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = wave & 1, ctl = wave >> 1;                // plane rows {2 half, 2 half + 1} / column tile inside the workgroup
-    const int ctg = (int)blockIdx.y * (CW / 16) + ctl;         // column tile of the layer
-    const int li = lane & 15, kk = lane >> 4;
-    const bool mfma_first = ((wave >> 2) & 1) != 0;            // waves w and w + 4 share a SIMD: one of each order on it
-
-    // ---- LDS starts as zeros: the halo rows of the slabs and the 8 padding rows of every plane
-    for (int i = tid; i < (int)(WINO_LDS / 16); i += CT) reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    int my_units = 0;
-    if ((int)blockIdx.x < units) my_units = (units - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
-    if (my_units == 0) return;
-    const int NG = my_units * NCHUNK;
-    auto unit_of = [&](int g) { return (int)blockIdx.x + (g / NCHUNK) * (int)gridDim.x; };
-
-    const float4* in4 = reinterpret_cast<const float4*>(in);
-    float4 st[NLD];
-    auto gload = [&](int g) {
-        const int u = unit_of(g), cc = g % NCHUNK;
-#pragma unroll
-        for (int q = 0; q < NLD; ++q) {
-            const int f = tid + q * CT;
-            st[q] = f < NPIECE ? bx_ld_stream(in4 + ((size_t)u * NCHUNK + cc) * NPIECE + f) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto lwrite = [&](int g) {
-        float* slab = slab0 + (g & 1) * SLAB_FLOATS;
-        int tq = tid;
-        asm volatile("" : "+v"(tq));      // destination addresses are recomputed (pure integer math): fewer live registers
-#pragma unroll
-        for (int q = 0; q < NLD; ++q) {
-            const int f = tq + q * CT;
-            if (f < NPIECE) {
-                const int p = f >> 2, part = f & 3;
-                const int h = p / BX_AZI, w = p - h * BX_AZI;
-                float* d = slab + ((h + 1) * WP + (w + 1)) * ROWF + part * 4;
-                *reinterpret_cast<float4*>(d) = st[q];
-                if (w == 0) *reinterpret_cast<float4*>(d + BX_AZI * ROWF) = st[q];                 // column 20 = column 0
-                else if (w == BX_AZI - 1) *reinterpret_cast<float4*>(d - BX_AZI * ROWF) = st[q];   // column -1 = column 19
-            }
-        }
-    };
-    // transform items of this thread: item = (x, tile, quad); t_x = d[ra] +- d[rb] down the columns, then along the row
-    int ia[NIT], ib[NIT], iv[NIT];
-    float isg[NIT];
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-        const int it = tid + k * CT;
-        ia[k] = -1; ib[k] = 0; iv[k] = 0; isg[k] = 0.f;
-        if (it < NITEM) {
-            const int x = it / (NT_ * 4), rem = it - x * (NT_ * 4);
-            const int t = rem >> 2, part = rem & 3;
-            const int tr = t / TC, tc = t - tr * TC;
-            const int ra = x == 0 ? 0 : (x == 2 ? 2 : 1);
-            const int rb = x == 0 ? 2 : (x == 1 ? 2 : (x == 2 ? 1 : 3));
-            isg[k] = x == 1 ? 1.0f : -1.0f;                    // fmaf(+-1, b, a) == a +- b exactly
-            ia[k] = ((2 * tr + ra) * WP + 2 * tc) * ROWF + part * 4;
-            ib[k] = ((2 * tr + rb) * WP + 2 * tc) * ROWF + part * 4;
-            iv[k] = (x * 4) * VPLANE + t * ROWF + part * 4;
-        }
-    }
-    auto transform = [&](int g) {                              // chunk g: slab buffer g & 1 -> plane set g & 1
-        const float* slab = slab0 + (g & 1) * SLAB_FLOATS;
-        float* Vp = V0 + (g & 1) * 16 * VPLANE;
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            if (ia[k] < 0) continue;
-            const float sg = isg[k];
-            float4 tj[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float4 a = *reinterpret_cast<const float4*>(slab + ia[k] + j * ROWF);
-                const float4 b = *reinterpret_cast<const float4*>(slab + ib[k] + j * ROWF);
-                tj[j] = make_float4(fmaf(sg, b.x, a.x), fmaf(sg, b.y, a.y), fmaf(sg, b.z, a.z), fmaf(sg, b.w, a.w));
-            }
-            float* vd = Vp + iv[k];
-            *reinterpret_cast<float4*>(vd) = make_float4(tj[0].x - tj[2].x, tj[0].y - tj[2].y, tj[0].z - tj[2].z, tj[0].w - tj[2].w);
-            *reinterpret_cast<float4*>(vd + VPLANE) = make_float4(tj[1].x + tj[2].x, tj[1].y + tj[2].y, tj[1].z + tj[2].z, tj[1].w + tj[2].w);
-            *reinterpret_cast<float4*>(vd + 2 * VPLANE) = make_float4(tj[2].x - tj[1].x, tj[2].y - tj[1].y, tj[2].z - tj[1].z, tj[2].w - tj[1].w);
-            *reinterpret_cast<float4*>(vd + 3 * VPLANE) = make_float4(tj[1].x - tj[3].x, tj[1].y - tj[3].y, tj[1].z - tj[3].z, tj[1].w - tj[3].w);
-        }
-    };
-
-    // bias of the four output slots 4 a .. 4 a + 3 (a = quad & 3) of column tile quad >> 2 this thread stores: slot s holds channel
-    // (s & 3) * 4 + (s >> 2) of the tile
-    const float* bq = bias + ((int)blockIdx.y * (CW / 16) + ((tid & 15) >> 2)) * 16 + (tid & 3);
-    const float4 b4 = make_float4(bq[0], bq[4], bq[8], bq[12]);
-    // B fragments: [chunk * 16 + plane][column tile][lane][4] (the layout of the direct kernels with 16 "taps"); this wave's planes
-    // are half * 8 + 0..7
-    const float4* wbase = reinterpret_cast<const float4*>(U) + ((size_t)(half * 8) * NT + ctg) * 64 + lane;
-    // A operand of row tile rt of plane half*8 + p: row rt*16 + li, slots 4 kk .. 4 kk + 3
-    const int aoff = ((half * 8 * VROWS + li) * ROWF + kk * 4) * 4;
-
-    f32x4 acc[8][3];
-    // the eight B fragments of a chunk are requested one chunk ahead: plane p's fragment of the NEXT chunk right after plane p's MFMAs
-    float4 bring[8];
-#pragma unroll
-    for (int p = 0; p < 8; ++p) bring[p] = wbase[((size_t)p * NT) * 64];      // chunk 0
-    auto mfma_chunk = [&](int g) {
-        int ccn = g % NCHUNK + 1;
-        ccn = ccn == NCHUNK ? 0 : ccn;                                              // chunk after this one (next unit: chunk 0)
-        const char* abase = reinterpret_cast<const char*>(V0 + (g & 1) * 16 * VPLANE) + aoff;
-        // 24 (plane, row tile) steps, A operand two steps ahead
-        f32x4 a0 = *reinterpret_cast<const f32x4*>(abase);
-        f32x4 a1 = *reinterpret_cast<const f32x4*>(abase + (16 * ROWF) * 4);
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const float4 bq = bring[p];
-#pragma unroll
-            for (int rt = 0; rt < 3; ++rt) {
-                const int stp = p * 3 + rt + 2;                                      // the step whose operand is requested now
-                f32x4 a2 = a0;
-                if (stp < 24) a2 = *reinterpret_cast<const f32x4*>(abase + (((stp / 3) * VROWS + (stp % 3) * 16) * ROWF) * 4);
-                acc[p][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bq.x, acc[p][rt], 0, 0, 0);
-                acc[p][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bq.y, acc[p][rt], 0, 0, 0);
-                acc[p][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bq.z, acc[p][rt], 0, 0, 0);
-                acc[p][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bq.w, acc[p][rt], 0, 0, 0);
-                a0 = a1; a1 = a2;
-                __builtin_amdgcn_sched_barrier(0);      // pins the order: without it the scheduler hoists every reload of `bring` and every
-                                                        // A read to the top of the chunk and the register demand doubles (spills between the MFMAs)
-            }
-            bring[p] = wbase[((size_t)(ccn * 16 + p) * NT) * 64];
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    // ---- prologue: slabs of chunks 0 and 1, V(0), chunk 2 on its way
-    gload(0);
-    __syncthreads();                 // zero fill complete
-    lwrite(0);
-    if (NG > 1) { gload(1); lwrite(1); }
-    __syncthreads();
-    transform(0);
-    if (NG > 2) gload(2);
-    __syncthreads();
-
-#pragma unroll 1
-    for (int g = 0; g < NG; ++g) {
-        const int cc = g % NCHUNK;
-        if (cc == 0) {
-#pragma unroll
-            for (int p = 0; p < 8; ++p)
-#pragma unroll
-                for (int rt = 0; rt < 3; ++rt) acc[p][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        if (g + 2 < NG) lwrite(g + 2);          // slab buffer g & 1: chunk g was transformed in the previous iteration
-        if (g + 3 < NG) gload(g + 3);
-        // ONE copy of the MFMA code (two copies make the accumulators change registers between them: twice the VGPRs)
-        if (!mfma_first && g + 1 < NG) transform(g + 1);
-        mfma_chunk(g);
-        if (mfma_first && g + 1 < NG) transform(g + 1);
-        __syncthreads();             // V(g + 1) and the slab of chunk g + 2 complete; plane set g & 1 is free
-        if (cc != NCHUNK - 1) continue;
-        // ---- output transform of the unit (wino_output above); E lives in the bytes of plane set g & 1, untouched by the next
-        //      transform until the helper's last barrier (the padding rows 40..47 of some planes then hold E data: they feed
-        //      accumulator rows that are never stored)
-        const int u = unit_of(g);
-        wino_output<3, NT_, RELU>(acc, V0 + (g & 1) * 16 * VPLANE, half, ctl, li, kk, tid, b4,
-                                  [&](int R, int j, int quad, const float4& y0, const float4& y1) {
-                                      const int tr = R / TC, tc = R - tr * TC;
-                                      float* ou = out + ((((size_t)u * NT + (int)blockIdx.y * (CW / 16) + (quad >> 2)) * BX_EA +
-                                                          (2 * tr) * BX_AZI + 2 * tc + j) * 16 + (quad & 3) * 4);
-                                      bx_st_stream(reinterpret_cast<float4*>(ou), y0);
-                                      if (2 * tr + 1 < BX_ELE) bx_st_stream(reinterpret_cast<float4*>(ou + BX_AZI * 16), y1);
-                                  });
-    }
-}
-
-template <int NCHUNK, int COUT, bool RELU>
-int launch_wino(bx_ctx* c, int layer, hipStream_t s, const ConvLayerDev& L, const float* in, int units, float* out)
-{
-    static_assert(COUT % CW == 0, "a workgroup covers 64 output channels");
-    if (L.nchunk != NCHUNK || L.cout != COUT || (L.relu != 0) != RELU || !L.Wwino) {
-        bx_set_error("winograd layer %d: geometry mismatch (%d chunks, %d channels)", layer, L.nchunk, L.cout);
-        return BX_ERR_STATE;
-    }
-    auto k = wino_kernel<NCHUNK, COUT, RELU>;
-    int& cap = c->wino_cap[layer];
-    if (cap == 0) {
-        BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WINO_LDS));
-        int occ = 0;
-        BX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, CT, WINO_LDS));
-        cap = (occ >= 1 ? occ : 1) * c->n_cu / (COUT / CW);
-        if (cap < 1) cap = 1;
-        if (c->conv_cap_override > 0 && c->conv_cap_override < cap) cap = c->conv_cap_override;
-    }
-    int grid = units < cap ? units : cap;
-    if (grid <= 0) return BX_OK;
-    hipLaunchKernelGGL(k, dim3(grid, COUT / CW), dim3(CT), WINO_LDS, s, in, units, L.Wwino, L.b, out, c->skip);
-    BX_LAUNCH_CHECK();
-    return BX_OK;
-}
 // ---------------------------------------------------------------------------------------------------- two units per workgroup
 // wino_pair_kernel: the Cylindrical_Net layer with TWO units per workgroup: 2 x 40 tiles fill FIVE MFMA row tiles exactly (the
 // one-unit kernel above pads 40 tiles to 48 rows: one MFMA in six multiplies padding).  Single-buffered slab (2 units) + V planes
@@ -760,29 +545,14 @@ int bxk_wino(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t
 {
     if (units_dev || max_units < 1) return -1;
     const ConvLayerDev& L = c->desc[layer];
-    // bit l = layer l on the two-units-per-workgroup kernel (default: all six; BX_WINO_PAIR=0 selects the one-unit pipelined
-    // kernel).  Measured per launch (K = 5000, one unit -> two units per workgroup): 3 chunks 268 -> 257 us; 4 chunks 343 -> 317 and
-    // 670 -> 627; 8 chunks 128 -> 128: 1 254 -> 1 131, 128 -> 64: 639 -> 566
-    static int pair_mask = -1;
-    if (pair_mask < 0) { const char* e = getenv("BX_WINO_PAIR"); pair_mask = e ? atoi(e) : 63; }
-    if ((pair_mask >> layer) & 1) {
-        switch (layer) {
-            case 0: return launch_wino_pair<3, 64, true>(c, layer, s, L, in, max_units, out);
-            case 1: return launch_wino_pair<4, 64, true>(c, layer, s, L, in, max_units, out);
-            case 2: return launch_wino_pair<4, 128, true>(c, layer, s, L, in, max_units, out);
-            case 3: return launch_wino_pair<8, 128, true>(c, layer, s, L, in, max_units, out);
-            case 4: return launch_wino_pair<8, 64, true>(c, layer, s, L, in, max_units, out);
-            case 5: return launch_wino_pair<4, 64, true>(c, layer, s, L, in, max_units, out);
-        }
-    }
     switch (layer) {
-        case 0: return launch_wino<3, 64, true>(c, layer, s, L, in, max_units, out);
-        case 1: return launch_wino<4, 64, true>(c, layer, s, L, in, max_units, out);
-        case 2: return launch_wino<4, 128, true>(c, layer, s, L, in, max_units, out);
-        case 3: return launch_wino<8, 128, true>(c, layer, s, L, in, max_units, out);
-        case 4: return launch_wino<8, 64, true>(c, layer, s, L, in, max_units, out);
-        case 5: return launch_wino<4, 64, true>(c, layer, s, L, in, max_units, out);
-        // layers 6 and 7 (32 output channels: half a workgroup) stay on the direct kernels
+        case 0: return launch_wino_pair<3, 64, true>(c, layer, s, L, in, max_units, out);
+        case 1: return launch_wino_pair<4, 64, true>(c, layer, s, L, in, max_units, out);
+        case 2: return launch_wino_pair<4, 128, true>(c, layer, s, L, in, max_units, out);
+        case 3: return launch_wino_pair<8, 128, true>(c, layer, s, L, in, max_units, out);
+        case 4: return launch_wino_pair<8, 64, true>(c, layer, s, L, in, max_units, out);
+        case 5: return launch_wino_pair<4, 64, true>(c, layer, s, L, in, max_units, out);
+        // layers 6 and 7 (32 output channels: half a workgroup) stay on the direct kernels in this form
     }
     return -1;
 }

@@ -25,7 +25,8 @@ class BxParams(C.Structure):
                 ("confidence", C.c_double), ("iter_n", C.c_int32), ("enable_early_exit", C.c_int32),
                 ("early_exit_min_inliers", C.c_int32), ("pose_refine", C.c_int32), ("max_points", C.c_int32),
                 ("pose_estimator", C.c_int32), ("kiss_resolution", C.c_double),
-                ("keypoint_tiles", C.c_int32), ("reserved0", C.c_int32)]
+                ("keypoint_tiles", C.c_int32), ("desc_conv_form", C.c_int32), ("pose_conv_form", C.c_int32),
+                ("cost_l0_form", C.c_int32)]
 
 
 class BxWeights(C.Structure):
@@ -37,7 +38,7 @@ class BxWeights(C.Structure):
 class BxResult(C.Structure):
     _fields_ = [("pose", C.c_double * 16), ("num_inliers", C.c_int32), ("num_mutual", C.c_int32),
                 ("num_inlier_ind", C.c_int32), ("scales_used", C.c_int32), ("ransac_iters", C.c_int32),
-                ("refine_iters", C.c_int32), ("status", C.c_int32), ("reserved", C.c_int32),
+                ("refine_iters", C.c_int32), ("status", C.c_int32), ("arith_forms", C.c_int32),
                 ("des_r", C.c_float * BX_MAX_SCALES)]
 
 
@@ -126,7 +127,21 @@ def params_from_cfg(cfg, max_points):
     p.kiss_resolution = float(cfg.match.get("kiss_resolution", 0.3))
     # not a reference option: 2..8 = latency form of the whole-pair call (FPS beside the descriptor work), see include/bufferx.h
     p.keypoint_tiles = int(cfg.test.get("keypoint_tiles", 0))
+    # arithmetic forms of the stages that have more than one (include/bufferx.h): cfg.arith, names as in config.ARITH_FORMS
+    from . import config as _config
+    ar = _config.arith_of(cfg)
+    p.desc_conv_form = _config.ARITH_FORMS["desc_conv"].index(ar["desc_conv"])
+    p.pose_conv_form = _config.ARITH_FORMS["pose_conv"].index(ar["pose_conv"])
+    p.cost_l0_form = _config.ARITH_FORMS["cost_l0"].index(ar["cost_l0"])
     return p
+
+
+def forms_of_result(res):
+    """bx_result.arith_forms -> {"desc_conv": name, "pose_conv": name, "cost_l0": name}"""
+    from . import config as _config
+    v = int(res.arith_forms)
+    return {"desc_conv": _config.ARITH_FORMS["desc_conv"][v & 255], "pose_conv": _config.ARITH_FORMS["pose_conv"][(v >> 8) & 255],
+            "cost_l0": _config.ARITH_FORMS["cost_l0"][(v >> 16) & 255]}
 
 
 def slot_perm():

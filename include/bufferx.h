@@ -72,8 +72,22 @@ typedef struct bx_params {
                                            * internal stream in that many launches (the first ends at num_points_radius_estimate)
                                            * and the descriptors of a tile of keypoints are computed while the next tile is still
                                            * being sampled.  Results are bit-identical in both forms. */
-    int32_t reserved0;
+    /* Arithmetic forms of the three stages that have more than one (no reference counterpart: the reference leaves the summation order
+     * of its convolutions to cuDNN / ATen).  Every form has its own restatement in the oracle (oracle/oracle.py takes the same
+     * names) and is bit-exact against it; the value in force is echoed in bx_result.arith_forms.  0 = the default of each. */
+    int32_t desc_conv_form;               /* Cylindrical_Net: BX_DESC_CONV_WINOGRAD43 (F(4x4,3x3), all 8 layers) | _WINOGRAD22 (F(2x2,3x3),
+                                           * the 6 layers with >= 64 output channels) | _DIRECT (fp32 fmaf chain chunk > tap > channel) */
+    int32_t pose_conv_form;               /* CostNet layers 1..5: BX_POSE_CONV_WINOGRAD (valid F(2x2,3x3)) | BX_POSE_CONV_DIRECT */
+    int32_t cost_l0_form;                 /* CostNet layer 0: BX_COST_L0_COLLAPSED (binary64 P - Q form) | BX_COST_L0_DIRECT (fp32
+                                           * convolution of the implicit cost volume) */
 } bx_params;
+#define BX_DESC_CONV_WINOGRAD43 0
+#define BX_DESC_CONV_WINOGRAD22 1
+#define BX_DESC_CONV_DIRECT 2
+#define BX_POSE_CONV_WINOGRAD 0
+#define BX_POSE_CONV_DIRECT 1
+#define BX_COST_L0_COLLAPSED 0
+#define BX_COST_L0_DIRECT 1
 
 /* BatchNorm-folded weights in kernel layout, HOST pointers (buffer-x_amd/weights.py: fold_and_pack).
  * Replaces test.py:86-94 load_state_dict + the nn.Conv/BatchNorm modules of models/patch_embedder.py:26-41
@@ -102,7 +116,7 @@ typedef struct bx_result {
     int32_t ransac_iters;     /* iterations visited by the last RANSAC call */
     int32_t refine_iters;
     int32_t status;           /* 0 ok; device-side error bits otherwise */
-    int32_t reserved;
+    int32_t arith_forms;      /* the arithmetic forms the pair was computed in: desc_conv_form | pose_conv_form << 8 | cost_l0_form << 16 */
     float des_r[BX_MAX_SCALES];
 } bx_result;
 

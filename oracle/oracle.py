@@ -181,31 +181,31 @@ def conv_wino_valid(x, W, bias, relu, D, fold):
     return out
 
 
-# CostNet layers 1..5 (3 x 3 kernels over the two azimuth-like axes): "winograd" (default, k_wino.hip) | "direct" (conv_kernel);
-# follows the product's switch BX_POSE_CONV
-POSE_CONV = os.environ.get("BX_POSE_CONV", "winograd")
+def _default_form(key):
+    import bufferx_amd.config as _c       # the product's knob table: the default of every arithmetic form lives in ONE place
+    return _c.ARITH_DEFAULT[key]
 
 
-def pose_conv(layer, x, tap, dims, W, bias, relu):
-    """CostNet layer `layer` (1..9) in the arithmetic the product is configured for; dims = input dims (n, k, l) of the layer."""
-    if POSE_CONV == "winograd" and 1 <= layer <= 5:
+def pose_conv(layer, x, tap, dims, W, bias, relu, form=None):
+    """CostNet layer `layer` (1..9) in the arithmetic form `form` of bx_params.pose_conv_form ("winograd": layers 1..5 as valid
+    F(2x2, 3x3) convolutions, wino_pose_kernel | "direct": conv_kernel); dims = input dims (n, k, l) of the layer."""
+    form = form or _default_form("pose_conv")
+    assert form in ("winograd", "direct"), form
+    if form == "winograd" and 1 <= layer <= 5:
         return conv_wino_valid(x, W, bias, relu, dims[0], dims[1])
     return conv(x, tap, W, bias, relu)
 
 
-# which restatement of the Cylindrical_Net layers the chain and the tests use -- it follows the product's switch (BX_DESC_CONV,
-# read by bx_create): "winograd" (default) = bxo_conv_wino (k_wino.hip), "direct" = fmaf chain over chunk > tap > channel (conv_kernel, k_conv.hip)
-DESC_CONV = os.environ.get("BX_DESC_CONV", "winograd43")
-
-
-def desc_conv(x, tap, W, bias, relu):
-    """One Cylindrical_Net layer in the arithmetic the product is configured for (k_wino.hip serves the layers with >= 64 output
-    channels; the two 32-channel layers stay on the direct kernels in either mode)."""
-    if np.asarray(W).shape[-1] >= 64:
-        if DESC_CONV == "winograd":
-            return conv_wino(x, W, bias, relu)          # F(2x2, 3x3)
-        if DESC_CONV != "direct":
-            return conv_wino43(x, W, bias, relu)        # F(4x4, 3x3), the default
+def desc_conv(x, tap, W, bias, relu, form=None):
+    """One Cylindrical_Net layer in the arithmetic form `form` of bx_params.desc_conv_form: "winograd43" = bxo_conv_wino43 for every
+    layer (k_wino43.hip), "winograd22" = bxo_conv_wino for the layers with >= 64 output channels (k_wino.hip; the two 32-channel layers
+    stay direct), "direct" = fmaf chain over chunk > tap > channel (conv_kernel, k_conv.hip)."""
+    form = form or _default_form("desc_conv")
+    assert form in ("winograd43", "winograd22", "direct"), form
+    if form == "winograd43":
+        return conv_wino43(x, W, bias, relu)
+    if form == "winograd22" and np.asarray(W).shape[-1] >= 64:
+        return conv_wino(x, W, bias, relu)
     return conv(x, tap, W, bias, relu)
 
 

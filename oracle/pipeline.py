@@ -6,13 +6,12 @@ stage by stage, on the C oracle.  Randomness is explicit (seed): permutation str
 RANSAC call c uses mix64(seed, 0x5AC0000 + c), the >200k-point subsample of the radius estimation
 uses stream 0x200 (the reference uses unseeded torch.randint, models/BUFFERX.py:664-665).
 """
-import os
 import numpy as np
 from . import oracle as O
 
-# which restatement of CostNet layer 0 the chain uses: "direct" = fp32 convolution of the materialised cost volume (the contract of
-# cost_l1_kernel), "collapsed" = bxo_cost_l0 (binary64 P - Q form)
-COST_L0 = os.environ.get("BX_ORACLE_COST_L0", "collapsed")
+def _arith(cfg):
+    import bufferx_amd.config as C        # pure-python knob table (no GPU code)
+    return C.arith_of(cfg)
 
 
 def _w():
@@ -30,7 +29,7 @@ def desc_forward(cloud, kpts, des_r, aligned, perm, pw, cfg, cap=None, tag=""):
     tap = W.cyl_tap_table(cfg.patch.ele_n, cfg.patch.azi_n)
     x = feat
     for L in pw["desc"]:
-        x = O.desc_conv(x, tap, L["W"], L["b"], L["relu"])     # direct or Winograd form, whichever the product runs (BX_DESC_CONV)
+        x = O.desc_conv(x, tap, L["W"], L["b"], L["relu"], form=_arith(cfg)["desc_conv"])     # cfg.arith: the form the product is configured for
     desc, equi = O.desc_head(x, pw["pool_w1"], pw["pool_b1"], pw["pool_w2"], pw["pool_b2"])
     if cap is not None:
         cap[tag + "idx"] = idx
@@ -46,7 +45,8 @@ def desc_forward(cloud, kpts, des_r, aligned, perm, pw, cfg, cap=None, tag=""):
 def pose_forward(s_equi, t_equi, s_mids, t_mids, pw, cfg, cap=None, tag=""):
     W = _w()
     layers = list(zip(pw["pose"], W.pose_geometry(cfg.patch.ele_n, cfg.patch.azi_n)))
-    if COST_L0 == "collapsed":
+    ar = _arith(cfg)
+    if ar["cost_l0"] == "collapsed":
         # layer 0 on the implicit cost volume: the collapsed binary64 form (bxo_cost_l0); layers 1..9 are explicit convolutions
         x = O.cost_l0(s_equi, t_equi, s_mids, t_mids, pw["pose"][0]["W"], pw["pose"][0]["b"], cfg.patch.ele_n, cfg.patch.azi_n)
         layers = layers[1:]
@@ -55,7 +55,7 @@ def pose_forward(s_equi, t_equi, s_mids, t_mids, pw, cfg, cap=None, tag=""):
     first = len(pw["pose"]) - len(layers)
     for li, (L, (dims, k, out)) in enumerate(layers):
         tap, _ = W.valid_tap_table(dims, k)
-        x = O.pose_conv(first + li, x, tap, dims, L["W"], L["b"], L["relu"])      # layers 1..5: Winograd or direct form (BX_POSE_CONV)
+        x = O.pose_conv(first + li, x, tap, dims, L["W"], L["b"], L["relu"], form=ar["pose_conv"])
     ind = O.soft_argmax(x, cfg.patch.azi_n)
     if cap is not None:
         cap[tag + "logits"] = x

@@ -8,8 +8,20 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def pytest_addoption(parser):
+    parser.addoption("--arith", default="", help="arithmetic forms for the whole run, e.g. --arith desc_conv=direct,pose_conv=direct "
+                     "(bufferx_amd.config.ARITH_FORMS; product and oracle both follow cfg.arith -- nothing reads the environment)")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    spec = config.getoption("--arith")
+    if spec:
+        import bufferx_amd.config as C
+        for kv in spec.split(","):
+            k, v = kv.split("=")
+            assert k in C.ARITH_FORMS and v in C.ARITH_FORMS[k], (k, v, C.ARITH_FORMS)
+            C.ARITH_DEFAULT[k] = v
 
 
 def _has_gpu():

@@ -25,12 +25,60 @@ def test_header_symbols_exported():
 
 
 def test_struct_layouts_match_header():
+    """ctypes mirrors == the C structs: sizes and the offset of EVERY field, taken from a C program compiled against include/bufferx.h."""
+    import subprocess
+    import tempfile
     from bufferx_amd import lib
-    # bx_params: 8 int32, 1+8+3+1 doubles, 6 int32, 1 double ; bx_result: 16 doubles + 8 int32 + 8 floats
-    assert C.sizeof(lib.BxParams) == 8 * 4 + 13 * 8 + 6 * 4 + 8 + 8
-    assert lib.BxParams.pose_estimator.offset == 156 and lib.BxParams.kiss_resolution.offset == 160 and lib.BxParams.keypoint_tiles.offset == 168
-    assert C.sizeof(lib.BxResult) == 16 * 8 + 8 * 4 + 8 * 4
-    assert lib.BxParams.delta.offset == 32 and lib.BxParams.confidence.offset == 32 + 8 * 12
+    structs = {"bx_params": lib.BxParams, "bx_result": lib.BxResult, "bx_capture": lib.BxCapture, "bx_weights": lib.BxWeights}
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "bufferx.h"', "int main(void) {"]
+    for cname, cls in structs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f, cname, f))
+    lines += ["return 0; }"]
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "o.c"), os.path.join(d, "o")
+        open(src, "w").write("\n".join(lines))
+        subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        got = dict(l.split() for l in subprocess.check_output([exe], text=True).splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for f, _ in cls._fields_:
+            assert int(got["%s.%s" % (cname, f)]) == getattr(cls, f).offset, (cname, f)
+    # the arithmetic forms sit behind keypoint_tiles; bx_result echoes them in the former reserved word
+    assert lib.BxParams.keypoint_tiles.offset == 168 and lib.BxParams.desc_conv_form.offset == 172 and lib.BxParams.cost_l0_form.offset == 180
+    assert C.sizeof(lib.BxParams) == 184 and lib.BxResult.arith_forms.offset == 156
+
+
+def test_arith_forms_table():
+    """cfg.arith names <-> bx_params values: defaults are value 0, unknown names are refused, the header's constants agree."""
+    import bufferx_amd
+    from bufferx_amd import lib, config
+    hdr = open(os.path.join(ROOT, "include", "bufferx.h")).read()
+    for macro, key, name in (("BX_DESC_CONV_WINOGRAD43", "desc_conv", "winograd43"), ("BX_DESC_CONV_WINOGRAD22", "desc_conv", "winograd22"),
+                             ("BX_DESC_CONV_DIRECT", "desc_conv", "direct"), ("BX_POSE_CONV_WINOGRAD", "pose_conv", "winograd"),
+                             ("BX_POSE_CONV_DIRECT", "pose_conv", "direct"), ("BX_COST_L0_COLLAPSED", "cost_l0", "collapsed"),
+                             ("BX_COST_L0_DIRECT", "cost_l0", "direct")):
+        v = int(re.search(r"#define %s (\d+)" % macro, hdr).group(1))
+        assert config.ARITH_FORMS[key][v] == name
+    cfg = bufferx_amd.make_cfg("3DMatch")
+    saved = dict(config.ARITH_DEFAULT)
+    try:
+        config.ARITH_DEFAULT.update({k: v[0] for k, v in config.ARITH_FORMS.items()})
+        cfg = bufferx_amd.make_cfg("3DMatch")
+        p = lib.params_from_cfg(cfg, 1000)
+        assert (p.desc_conv_form, p.pose_conv_form, p.cost_l0_form) == (0, 0, 0)
+        cfg.arith.desc_conv, cfg.arith.cost_l0 = "direct", "direct"
+        p = lib.params_from_cfg(cfg, 1000)
+        assert (p.desc_conv_form, p.pose_conv_form, p.cost_l0_form) == (2, 0, 1)
+        cfg.arith.pose_conv = "fast"
+        try:
+            lib.params_from_cfg(cfg, 1000)
+            assert False, "unknown form accepted"
+        except ValueError:
+            pass
+    finally:
+        config.ARITH_DEFAULT.update(saved)
 
 
 def test_keypoint_tile_bounds():
@@ -77,6 +125,8 @@ def test_error_path_without_gpu():
     assert rc != 0 and len(so.bx_last_error()) > 0
     p.rad_n = 4
     assert so.bx_create(0, C.byref(p), C.byref(h)) == 1  # BX_ERR_ARG: geometry other than 3/7/20 is rejected
+    p.rad_n, p.desc_conv_form = 3, 7
+    assert so.bx_create(0, C.byref(p), C.byref(h)) == 1 and b"arithmetic form" in so.bx_last_error()
 
 
 def test_slot_permutation_is_involution_free_bijection():

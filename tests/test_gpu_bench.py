@@ -42,7 +42,13 @@ def test_world2_records_equal_world1(tmp_path):
         assert j["roofline"]["bound"] == "mfma" and j["roofline_neighbour_gather"]["bound"] == "hbm"
         assert set(j["work"]) >= {"mean_m_per_scale", "mean_M", "mean_C", "mean_ransac_iters"}
         lf = j["p50_ms_per_pair_latency_form"]
-        assert lf["results_identical_to_throughput_form"] is True and lf["p50_ms"] > 0 and j["p50_ms_per_pair_inflight1"] > 0
+        assert lf["results_identical_to_throughput_form"] is True and lf["p50_ms"] > 0
+        # p50 of the metric = service time of one pair; the queueing latency and the in-flight sweep have their own keys
+        assert j["p50_ms_per_pair"] > 0 and j["p50_ms_per_pair_queueing_at_inflight"]["p50_ms"] >= j["p50_ms_per_pair"] * 0.5
+        assert [e["inflight"] for e in j["inflight_sweep"]] == [1, 2] and all(e["pairs_per_s"] > 0 for e in j["inflight_sweep"])
+        # the roofline fields are fractions of a peak: flops ISSUED on the matrix pipe, never above 1
+        assert 0 < j["roofline"]["frac"] <= 1.0 and 0 < j["roofline_costnet"]["frac"] <= 1.0 and j["roofline"]["algorithmic_rate_x_peak"] > 0
+        assert j["config"]["arithmetic_forms"] == {"desc_conv": "winograd43", "pose_conv": "winograd", "cost_l0": "collapsed"}
     assert j1["registered_ok"] == j2["registered_ok"] == j3["registered_ok"]
     assert j1["host_ms_per_pair"] > 0
     e2e = j1["e2e_pairs_per_s"]          # files -> poses leg (N = 1 only): both RNG modes produce a rate

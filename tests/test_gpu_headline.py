@@ -225,7 +225,7 @@ def test_headline_vs_reference(headline, bx, golden_dir):
     tests/golden/ref_harness.py): identical counts (RANSAC inliers, accumulated mutual matches, consensus set, scales used), radii,
     per-scale mutual sets and consensus set, and the pose within the north-star tolerance 1e-4 deg / 1e-4 m.  The number of
     descriptor rows that differ beyond 2e-5 (a point within an ulp of a radius / voxel bound decided differently by the reference's
-    torch / numpy arithmetic) is REPORTED, not asserted: DESIGN.md section 4 quotes it."""
+    torch / numpy arithmetic) is reported AND bounded (0.4 % of the sampled rows): DESIGN.md section 4 quotes it."""
     g = np.load(os.path.join(golden_dir, headline["name"] + ".npz"))
     pair, used = headline["pair"], headline["used"]
     assert np.array_equal(pair["src"][:8], g["src_head"]) and np.array_equal(pair["tgt"][:8], g["tgt_head"])
@@ -249,6 +249,9 @@ def test_headline_vs_reference(headline, bx, golden_dir):
             bad += int((d > 2e-5).sum())
         report[f"scale{scale}"] = dict(mutual_gpu=len(a), mutual_ref=len(b), mutual_common=len(a & b), desc_rows_off=bad, desc_rows_checked=2 * len(d))
         assert a == b, report
+        # bounded, not just reported (advisor, round 3): at most 0.4 % of the sampled descriptor rows may sit beyond 2e-5 (round 3 saw
+        # 0.1 % on the un-aligned indoor case -- ulp-bound patch decisions -- and none on the z-aligned ones)
+        assert bad <= 0.004 * 2 * len(d), report
         if len(a) == len(b) and np.array_equal(_np(cap["s_mids"])[:m], gs):
             report[f"scale{scale}"]["ind_max_diff"] = float(np.abs(_np(cap["ind"])[:m] - g[f"s{scale}_ind"]).max())
     k = 0
@@ -285,8 +288,7 @@ def test_conv_layers_group_walk(bx, packed, oracle, monkeypatch):
     W = bx.weights
     cfg = _headline_cfg(bx)
     rng = np.random.default_rng(3)
-    for cap_env, conv32 in (("48", "0"), (None, "0"), ("48", "1"), (None, "1")):      # BX_CONV32=1: the 32x32x2 kernels of k_conv32.hip
-        monkeypatch.setenv("BX_CONV32", conv32)
+    for cap_env in ("48", None):
         if cap_env:
             monkeypatch.setenv("BX_CONV_PERSIST_CAP", cap_env)
         else:
@@ -306,7 +308,7 @@ def test_conv_layers_group_walk(bx, packed, oracle, monkeypatch):
                 ref = oracle.desc_conv(lib.chunked_to_logical(_np(x[ts])), tap, L["W"], L["b"], L["relu"])
                 assert np.array_equal(lib.chunked_to_logical(_np(y[ts])), ref), ("desc", l, cap_env)
                 x = y
-            if cap_env is None or conv32 == "1":
+            if cap_env is None:
                 continue
             # Pose: layer 0 consumes the implicit cost volume (bx_pose_net); layers 1..9 through bx_conv_layer
             units = 1400

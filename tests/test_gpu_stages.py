@@ -233,9 +233,51 @@ def test_pose_conv_layer_exact(ctx, oracle, bx, packed, layer):
     rng = np.random.default_rng(100 + layer)
     units = 37 if layer >= 5 else 5
     x = rng.standard_normal((units, nch, int(np.prod(dims)), 16)).astype(np.float32)
-    ref = oracle.pose_conv(layer, x, tap, dims, L["W"], L["b"], L["relu"])      # layers 1..5: Winograd or direct form (BX_POSE_CONV)
+    ref = oracle.pose_conv(layer, x, tap, dims, L["W"], L["b"], L["relu"])      # layers 1..5: the run's pose_conv form
     out = ctx.conv_layer(1, layer, lib.logical_to_chunked(x), ref.shape)
     assert np.array_equal(lib.chunked_to_logical(_np(out)), ref)
+
+
+@pytest.mark.parametrize("form", ["winograd43", "winograd22", "direct"])
+def test_desc_conv_every_form(oracle, bx, packed, form):
+    """bx_params.desc_conv_form: each of the three forms of the Cylindrical_Net layers against ITS restatement, all 8 layers chained
+    (13 units: ragged last group of the three-unit F(4x4) kernel and of the two-unit F(2x2) kernel), and the form echoed by the context."""
+    from bufferx_amd import lib
+    cfg = _cfg(bx, K=64, P=64, S=1, nk=64)
+    cfg.arith.desc_conv = form
+    c = lib.Context(cfg, max_points=4096, device=0, packed_weights=packed)
+    try:
+        rng = np.random.default_rng(40)
+        x = np.abs(rng.standard_normal((13, 3, 140, 16))).astype(np.float32)
+        for layer, L in enumerate(packed["desc"]):
+            ref = oracle.desc_conv(x, bx.weights.cyl_tap_table(), L["W"], L["b"], L["relu"], form=form)
+            out = c.conv_layer(0, layer, lib.logical_to_chunked(x), ref.shape)
+            assert np.array_equal(lib.chunked_to_logical(_np(out)), ref), (form, layer)
+            x = ref
+        assert c.params.desc_conv_form == bx.config.ARITH_FORMS["desc_conv"].index(form)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("form", ["winograd", "direct"])
+def test_pose_conv_every_form(oracle, bx, packed, form):
+    """bx_params.pose_conv_form: CostNet layers 1..5 in both forms against their restatements."""
+    from bufferx_amd import lib
+    cfg = _cfg(bx, K=64, P=64, S=1, nk=64)
+    cfg.arith.pose_conv = form
+    c = lib.Context(cfg, max_points=4096, device=0, packed_weights=packed)
+    try:
+        for layer in range(1, 6):
+            L = packed["pose"][layer]
+            dims, k, _ = bx.weights.pose_geometry()[layer]
+            tap, od = bx.weights.valid_tap_table(dims, k)
+            rng = np.random.default_rng(200 + layer)
+            x = rng.standard_normal((7, L["W"].shape[0], int(np.prod(dims)), 16)).astype(np.float32)
+            ref = oracle.pose_conv(layer, x, tap, dims, L["W"], L["b"], L["relu"], form=form)
+            out = c.conv_layer(1, layer, lib.logical_to_chunked(x), ref.shape)
+            assert np.array_equal(lib.chunked_to_logical(_np(out)), ref), (form, layer)
+    finally:
+        c.close()
 
 
 def test_desc_net(ctx, oracle, bx, packed):
@@ -269,10 +311,10 @@ def test_mutual(ctx, oracle):
 
 # ------------------------------------------------------------------ CostNet + soft-argmax (row 12)
 @pytest.mark.parametrize("form", ["collapsed", "direct"])
-def test_pose_net(oracle, bx, packed, form, monkeypatch):
+def test_pose_net(oracle, bx, packed, form):
     """CostVolume + CostNet + soft-argmax (models/BUFFERX.py:39-69, models/patchnet.py:192-210), logits and ind bit-exact.
     collapsed: layer 0 = bxo_cost_l0 (binary64 P - Q form, k_cost.hip, the default); direct: layer 0 = the fp32 convolution of the
-    materialised cost volume (cost_l1_kernel, BX_COST_L0=direct)."""
+    materialised cost volume (cost_l1_kernel, cfg.arith.cost_l0 = "direct")."""
     import torch
     from bufferx_amd import lib
     rng = np.random.default_rng(5)
@@ -295,13 +337,13 @@ def test_pose_net(oracle, bx, packed, form, monkeypatch):
     first = 10 - len(layers)
     for li, (L, (dims, k, _)) in enumerate(layers):
         tap, _ = bx.weights.valid_tap_table(dims, k)
-        x = oracle.pose_conv(first + li, x, tap, dims, L["W"], L["b"], L["relu"])
+        x = oracle.pose_conv(first + li, x, tap, dims, L["W"], L["b"], L["relu"])      # the run's pose_conv form (conftest --arith)
     rind = oracle.soft_argmax(x)
     smp = np.zeros(K, np.int32); smp[:m] = sm
     tmp = np.zeros(K, np.int32); tmp[:m] = tm
-    if form == "direct":
-        monkeypatch.setenv("BX_COST_L0", "direct")
-    c = lib.Context(_cfg(bx, K=64, P=64, S=1, nk=64), max_points=4096, device=0, packed_weights=packed)
+    cfg = _cfg(bx, K=64, P=64, S=1, nk=64)
+    cfg.arith.cost_l0 = form
+    c = lib.Context(cfg, max_points=4096, device=0, packed_weights=packed)
     try:
         ind, logits = c.pose_net(se, te, smp, tmp, torch.tensor([m], dtype=torch.int32), K, want_logits=True)
         assert np.array_equal(lib.chunked_to_logical(_np(logits))[:m], x)

@@ -103,27 +103,3 @@ def test_capture_refused_in_latency_form(bx, packed):
     with pytest.raises(lib.BxError):       # refused when the capture is set, not later inside bx_register_pair
         ctx.set_capture(0, 0, max(ns, nt))
     ctx.close()
-
-
-def test_tiled_pair_with_conv32(bx, packed, monkeypatch):
-    """BX_CONV32=1 (32x32x2 loader/compute kernels, ticketed group walk with ONE counter pair per context and layer) together with
-    the latency form, whose source and target chains run the same layer concurrently on two streams: the chains must not draw
-    tickets from each other's launches -- results identical to the throughput form with the 16x16x4 kernels."""
-    from bufferx_amd import lib
-    K, P, S, nk = 1200, 64, 2, 96           # 1200 units: several unit groups per workgroup of the 32x32x2 kernels
-    cfg = _cfg(bx, K, P, S, [5, 2], nk, False)
-    pair = bx.synth.make_pair(13, "indoor", n_target=20000, shared=True)
-    ns, nt = len(pair["src"]), len(pair["tgt"])
-    rng = np.random.default_rng(8)
-    ps = np.stack([rng.permutation(ns) for _ in range(S)]).astype(np.int32)
-    pt = np.stack([rng.permutation(nt) for _ in range(S)]).astype(np.int32)
-    out = []
-    for conv32, t in (("0", 0), ("1", 0), ("1", 3)):
-        monkeypatch.setenv("BX_CONV32", conv32)
-        c = copy.deepcopy(cfg)
-        c.test.keypoint_tiles = t
-        ctx = lib.Context(c, max_points=max(ns, nt), device=0, packed_weights=packed)
-        for _ in range(2):
-            out.append(_fields(ctx.register_pair(pair["src"], pair["tgt"], pair["aligned_z"], ps, pt, 21)))
-        ctx.close()
-    assert all(o == out[0] for o in out) and out[0][2] > 0

@@ -104,11 +104,6 @@ def main():
             buf = (C.c_int64 * 512)()
             ctx.lib.bx_debug_read(ctx.handle, buf, 512)
             a = np.array(buf[:]).reshape(16, 32)
-            if os.environ.get("BX_CONV32", "1") != "0":
-                d = a[:, 1:18].astype(np.float64)
-                print("conv32 layer-3 stamps of one group, compute wave 0 (median cycles over 16 workgroups): " +
-                      " | ".join("c%d taps %d bar %d" % (c, np.median(d[:, 2 * c] - (d[:, 2 * c - 1] if c else 0)), np.median(d[:, 2 * c + 1] - d[:, 2 * c])) for c in range(8)))
-                print("  group total %d ; per-wg totals %s" % (np.median(d[:, 15]), d[:, 15].astype(int).tolist()))
             print("conv layer-1 stamps (median cycles over 16 workgroups): prologue %d | " % np.median(a[:, 1]) +
                   " ".join("c%d taps %d bar %d" % (c, np.median(a[:, 2 + 2 * c]), np.median(a[:, 3 + 2 * c])) for c in range(4)) + " | end %d" % np.median(a[:, 10]))
         flops = 2.0 * 59.351e6 * K
