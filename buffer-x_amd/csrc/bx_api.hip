@@ -54,8 +54,9 @@ int bx_xcd_pair_sharing(int device, int pair)
     std::lock_guard<std::mutex> lk(g_slot_mu);
     return g_slot_use[device][pair];
 }
-static int xcd_slot_take(int device)
-{
+int bx_xcd_slot_take(int device)      // called by the FIRST furthest-point-sampling launch of a context (k_fps.hip): contexts that never sample
+{                                     // (harness.py's preparation-only context) do not count towards the sharing of an XCD pair
+    if (device < 0 || device >= 64) return 0;
     std::lock_guard<std::mutex> lk(g_slot_mu);
     int best = 0;
     for (int p = 1; p < 4; ++p) if (g_slot_use[device][p] < g_slot_use[device][best]) best = p;
@@ -472,7 +473,8 @@ int bx_create(int device_id, const bx_params* params, bx_ctx** out)
     memset(c, 0, sizeof(*c));
     c->device = device_id;
     c->p = p;
-    if (device_id < 64) { c->fps_xcd_pair = xcd_slot_take(device_id); g_live[device_id].fetch_add(1); }
+    c->fps_xcd_pair = -1;              // taken lazily by the first FPS launch
+    if (device_id < 64) g_live[device_id].fetch_add(1);
     const int rc = create_impl(c, device_id);
     if (rc != BX_OK) {
         // bx_destroy releases whatever had been allocated; it must not clobber the message of the failure
@@ -491,7 +493,7 @@ int bx_destroy(bx_ctx* c)
     if (!c) return BX_OK;
     BxDevScope ds(c->device);
     (void)hipDeviceSynchronize();
-    if (c->device >= 0 && c->device < 64) { g_live[c->device].fetch_sub(1); xcd_slot_release(c->device, c->fps_xcd_pair); }
+    if (c->device >= 0 && c->device < 64) { g_live[c->device].fetch_sub(1); if (c->fps_xcd_pair >= 0) xcd_slot_release(c->device, c->fps_xcd_pair); }
     bxk_pre_release(c);
     if (c->prof) {
         auto* v = static_cast<std::vector<ProfEvt>*>(c->prof);

@@ -148,7 +148,7 @@ struct bx_ctx {
     unsigned long long* fps_slots;      // cross-workgroup exchange granules
     unsigned long long* fps_hello;      // [2][64] placement handshake granules (k_fps.hip)
     int fps_attr_set;
-    int fps_xcd_pair;                   // 0..3: the XCD pair {2p, 2p+1} the co-located FPS launches of this context aim at (creation order mod 4)
+    int fps_xcd_pair;                   // 0..3: the XCD pair {2p, 2p+1} the co-located FPS launches of this context aim at; -1 until its first FPS launch
     int32_t* ransac_inl;                // [RANSAC_BATCH]
     double* ransac_err;                 // [RANSAC_BATCH]
     double* ransac_T;                   // [RANSAC_BATCH][12]
@@ -200,6 +200,7 @@ constexpr int BX_RANSAC_BATCH = 4096;
 int bxk_fps(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* n, int nclouds, int m, int32_t* const* idx_out,
             float* const* kpts_out);
 int bx_live_contexts(int device);   // contexts alive on the device in this process (bx_api.hip)
+int bx_xcd_slot_take(int device);                // least-used XCD pair of the device; released by bx_destroy
 int bx_xcd_pair_sharing(int device, int pair);   // live contexts of the device whose co-located FPS launches aim at this XCD pair
 int bxk_fps_range(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* n, int nclouds, int j0, int j1, int m,
                   int32_t* const* idx_out, float* const* kpts_out);

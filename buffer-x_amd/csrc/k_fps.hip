@@ -437,6 +437,7 @@ int bxk_fps_range(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* 
     const int coloc = ec ? atoi(ec) : 1;
     int gmax = 0;
     for (int i = 0; i < nclouds; ++i) gmax = a.G[i] > gmax ? a.G[i] : gmax;
+    if (c->fps_xcd_pair < 0) c->fps_xcd_pair = bx_xcd_slot_take(c->device);
     const int sharing = bx_xcd_pair_sharing(c->device, c->fps_xcd_pair);     // live contexts aimed at the same XCD pair
     a.colocate = (coloc && gmax > 1 && gmax * (sharing < 1 ? 1 : sharing) <= 32) ? 1 : 0;
     a.hello = c->fps_hello;

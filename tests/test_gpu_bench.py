@@ -54,3 +54,24 @@ def test_world2_records_equal_world1(tmp_path):
     e2e = j1["e2e_pairs_per_s"]          # files -> poses leg (N = 1 only): both RNG modes produce a rate
     assert e2e.get("device", 0) > 0 and e2e.get("reference", 0) > 0, e2e
     assert "e2e_pairs_per_s" not in j2
+
+
+def test_world8_on_one_gpu_equals_world1(tmp_path):
+    """De-risking the 8-GPU run without an 8-GPU box (round 4): `python bench.py --gpus 8` at the REAL headline configuration (K = 5000,
+    P = 1024, 3 scales), eight ranks x four pairs in flight all on the ONE MI355X of the test box (gloo collectives): 32 contexts and HIP
+    streams and eight processes' multi-workgroup FPS launches (XCD co-location + bounded spins) coexist without a device-side failure
+    (bx_result.status is checked per pair by bench.py), the pair sharding + the one all-gather give exactly the records of a
+    single-rank run of the same 16 pairs, and the host cost per pair under that load is reported."""
+    BIG = ["--distinct", "8", "--inflight", "4", "--warmup", "2", "--no-cpu-baseline", "--e2e-pairs", "0", "--latency-tiles", "0",
+           "--inflight-sweep", ""]
+    r1, r8 = str(tmp_path / "w1.npy"), str(tmp_path / "w8.npy")
+    j1 = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "16", "--dump-records", r1] + BIG, {})
+    j8 = _run([sys.executable, "bench.py", "--gpus", "8", "--steps", "2", "--dump-records", r8] + BIG,
+              {"BX_DIST_BACKEND": "gloo", "BX_BENCH_SAME_GPU": "1"}, timeout=1500)
+    a, b = np.load(r1), np.load(r8)
+    assert a.shape == b.shape == (16, 24)
+    keep = [i for i in range(24) if i != 22]                      # column 22 = model_ms (a measurement)
+    assert np.array_equal(a[:, keep], b[:, keep])
+    assert j8["n_gpus"] == 8 and j8["registered_ok"] == j1["registered_ok"]
+    print("\nWORLD8_SAME_GPU", json.dumps({"host_ms_per_pair_world8": j8["host_ms_per_pair"], "host_ms_per_pair_world1": j1["host_ms_per_pair"],
+                                          "pairs_per_s_world8_one_gpu": j8["value"], "pairs_per_s_world1": j1["value"]}))
