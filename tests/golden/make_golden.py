@@ -53,14 +53,15 @@ CASES = {
     # BASELINE configs[2] geometry at its real size: two ~120k-point LiDAR sweeps, the reference's KITTI configuration (aligned z,
     # confidence 1.0 = all 50 000 RANSAC iterations, no refinement -> binary64 pose), 3 scales, 5000 keypoints, 1024 points per patch
     "kitti_cfg2": ("KITTI", "kitti_full", 0, 100, dict(num_fps=5000, num_points_per_patch=1024, sub_stride=256, row_stride=4)),
-    # round 4: more pairs at a size where matching is no longer sparse (1 000 - 1 500 keypoints, 3 scales, the reference's own defaults
-    # otherwise), other seeds / densities, so that "F(4x4, 3x3) keeps the reference's mutual and consensus sets" rests on more than three
-    # real-size pairs; "mid_low_overlap" is a 3DLoMatch-like pair (15 % overlap): a consensus set of a few members.  The small whole-pair
+    # round 4: more pairs at a size where matching is no longer sparse (1 000 - 1 500 keypoints on 4 000 - 6 000-point fragments: a quarter of
+    # the keypoints coincide, so the pairs REGISTER with the seeded random weights; 3 scales, the reference's own defaults otherwise), other
+    # seeds / densities, so that "F(4x4, 3x3) keeps the reference's mutual and consensus sets" rests on more than three real-size pairs;
+    # "mid_low_overlap" is a 3DLoMatch-like pair (30 % overlap) that does NOT register: a consensus set of seven members.  The small whole-pair
     # tests and the oracle pipeline run these end to end (tests/test_gpu_pipeline.py, tests/test_oracle_golden.py).
-    "mid_shared_a": ("3DMatch", "indoor_shared", 12000, 201, dict(num_fps=1200, num_points_per_patch=256, num_points_radius_estimate=600, sub_stride=64, row_stride=2)),
-    "mid_shared_b": ("3DMatch", "indoor_shared", 16000, 202, dict(num_fps=1500, num_points_per_patch=256, num_points_radius_estimate=600, sub_stride=64, row_stride=2)),
-    "mid_shared_c": ("3DMatch", "indoor_shared", 9000, 203, dict(num_fps=1000, num_points_per_patch=512, num_points_radius_estimate=500, sub_stride=64, row_stride=2)),
-    "mid_low_overlap": ("3DLoMatch", "indoor_shared_low", 14000, 204, dict(num_fps=1500, num_points_per_patch=256, num_points_radius_estimate=600, sub_stride=64, row_stride=2)),
+    "mid_shared_a": ("3DMatch", "indoor_shared", 5000, 201, dict(num_fps=1200, num_points_per_patch=256, num_points_radius_estimate=600, sub_stride=64, row_stride=2)),
+    "mid_shared_b": ("3DMatch", "indoor_shared", 6000, 202, dict(num_fps=1500, num_points_per_patch=256, num_points_radius_estimate=600, sub_stride=64, row_stride=2)),
+    "mid_shared_c": ("3DMatch", "indoor_shared", 4000, 203, dict(num_fps=1000, num_points_per_patch=512, num_points_radius_estimate=500, sub_stride=64, row_stride=2)),
+    "mid_low_overlap": ("3DLoMatch", "indoor_shared_low", 5000, 204, dict(num_fps=1500, num_points_per_patch=256, num_points_radius_estimate=600, sub_stride=64, row_stride=2)),
     "mid_kitti": ("KITTI", "outdoor_mid", 0, 205, dict(num_fps=1000, num_points_per_patch=256, num_points_radius_estimate=500, iter_n=8000, sub_stride=64, row_stride=2)),
 }
 
@@ -83,7 +84,7 @@ def case_inputs(name):
     elif kind == "indoor_shared":
         pair = bufferx_amd.synth.make_pair(seed, "indoor", n_target=n, shared=True)
     elif kind == "indoor_shared_low":
-        pair = bufferx_amd.synth.make_pair(seed, "indoor", n_target=n, shared=True, overlap=0.15)
+        pair = bufferx_amd.synth.make_pair(seed, "indoor", n_target=n, shared=True, overlap=0.3)
     elif kind == "outdoor_mid":
         pair = bufferx_amd.synth.make_pair(seed, "outdoor", voxel=0.15)
     elif kind == "tiers":

@@ -30,7 +30,16 @@ CASES = {
     # BASELINE configs[0] (1 scale, 512 keypoints, 512 points per patch, RANSAC + refinement), minted by the reference's own forward
     "baseline_cfg0": ("3DMatch", "indoor", 20000, 21, True,
                       dict(num_fps=512, num_points_per_patch=512, num_scales=1, search_radius_thresholds=[5]), dict(iter_n=4000)),
+    # round 4: reference-minted pairs at 1 000 - 1 500 keypoints x 3 scales (every other knob the dataset's default), incl. a 30 %-overlap
+    # pair (not registered: seven consensus members) and an outdoor one with all 8 000 RANSAC iterations: matching is no longer sparse, consensus sets of a handful of members
+    "mid_shared_a": ("3DMatch", "shared", 5000, 201, False, dict(num_fps=1200, num_points_per_patch=256, num_points_radius_estimate=600), dict()),
+    "mid_shared_b": ("3DMatch", "shared", 6000, 202, False, dict(num_fps=1500, num_points_per_patch=256, num_points_radius_estimate=600), dict()),
+    "mid_shared_c": ("3DMatch", "shared", 4000, 203, False, dict(num_fps=1000, num_points_per_patch=512, num_points_radius_estimate=500), dict()),
+    "mid_low_overlap": ("3DLoMatch", "shared_low", 5000, 204, False, dict(num_fps=1500, num_points_per_patch=256, num_points_radius_estimate=600), dict()),
+    "mid_kitti": ("KITTI", "outdoor_mid", 0, 205, False, dict(num_fps=1000, num_points_per_patch=256, num_points_radius_estimate=500), dict(iter_n=8000)),
 }
+# the mid-size cases (~20 s each through the oracle pipeline on 8 cores; row tolerance as baseline_cfg0, tests/test_oracle_golden.py)
+MID = ("mid_shared_a", "mid_shared_b", "mid_shared_c", "mid_low_overlap", "mid_kitti")
 
 
 def make_case(bx, name):
@@ -42,6 +51,12 @@ def make_case(bx, name):
         cfg.match[k] = v
     if kind == "indoor":
         pair = bx.synth.make_pair(seed, "indoor", n_target=n, identical=identical)
+    elif kind == "shared":
+        pair = bx.synth.make_pair(seed, "indoor", n_target=n, shared=True)
+    elif kind == "shared_low":
+        pair = bx.synth.make_pair(seed, "indoor", n_target=n, shared=True, overlap=0.3)
+    elif kind == "outdoor_mid":
+        pair = bx.synth.make_pair(seed, "outdoor", voxel=0.15)
     else:
         pair = bx.synth.make_pair(seed, "outdoor", voxel=0.6)
     return cfg, pair, seed
@@ -72,7 +87,10 @@ def test_pair_matches_oracle_and_golden(bx, packed, oracle, golden_dir, name):
     # and within tolerance of the REAL reference code's output (golden fixture)
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     assert np.array_equal(pair["src"][:8], g["src_head"]) and np.array_equal(pair["tgt"][:8], g["tgt_head"])
-    assert (n_inl, n_mut, n_ind, scales) == (int(g["num_inliers"]), int(g["num_mutual"]), int(g["num_inlier_ind"]), int(g["scales_used"]))
+    assert (n_inl, n_ind, scales) == (int(g["num_inliers"]), int(g["num_inlier_ind"]), int(g["scales_used"]))
+    # mid-size cases: a match of a keypoint whose descriptor the reference's torch / numpy arithmetic perturbs (ulp-bound patch decision)
+    # may differ -- bounded as in tests/test_oracle_golden.py, where the sets are compared member by member
+    assert abs(n_mut - int(g["num_mutual"])) <= (3 * scales if name in MID else 0)
     assert np.allclose(des_r[:scales], g["des_r"][:scales], atol=1e-6)
     # north_star tolerance: 1e-4 deg / 1e-4 m
     rre, rte = bx.synth.pose_difference(pose, g["pose"])    # well-conditioned at zero (synth.py)
