@@ -161,7 +161,7 @@ void carve(bx_ctx* c, char* base, size_t* total)
     c->ball_st_cnt = (size_t)BX_BALL_NCELL + 2 * 2048;
     c->ball_st_bsum = BX_BALL_NCELL / 2048 + 2;
     c->ball_st_pts = (NMAX + 63) & ~(size_t)63;
-    c->ball_st_tab = KM * 512;                    // k_ball.hip NPMAX pieces per keypoint
+    c->ball_st_tab = KM * 256;                    // k_ball.hip NPMAX pieces per keypoint
     c->ball_st_num = KM;
     c->ball_bbox_part = cv.take<float>(2 * 64 * 6);
     c->ball_grid = cv.take<BallGrid>(NS);
@@ -171,7 +171,6 @@ void carve(bx_ctx* c, char* base, size_t* total)
     c->ball_cellrank = cv.take<int2>(NS * c->ball_st_pts);
     c->ball_ptab = cv.take<int2>(NS * c->ball_st_tab);
     c->ball_pnum = cv.take<int32_t>(NS * c->ball_st_num);
-    c->ball_pepo = cv.take<int32_t>(NS * c->ball_st_num * 8);
     c->ball_pts4 = cv.take<float4>(NS * c->ball_st_pts);
     c->ball_sorted = cv.take<float4>(NS * c->ball_st_pts);
     c->ball_dbg = cv.take<long long>(64 * 8);

@@ -78,11 +78,10 @@ struct PairState {
 };
 
 // uniform grid of the neighbour gather (k_ball.hip), rebuilt per launch on the device
-constexpr int BX_BALL_NCELL = 1 << 19;     // capacity of a set's count / start tables: cells x index epochs
+constexpr int BX_BALL_NCELL = 1 << 17;
 struct BallGrid {
     float ox, oy, oz, inv_h, rpad;
-    int32_t dx, dy, dz, ncells;         // ncells = dx * dy * dz cells PER index epoch
-    int32_t epochs, tcells;             // index epochs of the set (k_ball.hip), tcells = ncells * epochs entries of the count / start tables
+    int32_t dx, dy, dz, ncells;
 };
 // tuning knob (env BX_BALL_DIV, read once): cell edge = padded radius / div  (1..3)
 int bx_ball_div();
@@ -165,10 +164,8 @@ struct bx_ctx {
     int32_t *ball_cnt, *ball_start;     // [nsets][BX_BALL_NCELL + 2 tiles]; cnt is all zeros between launches
     int32_t* ball_bsum;                 // [nsets] per scan tile
     int2* ball_cellrank;                // [nsets][max_points]
-    int2* ball_ptab;                    // [nsets][num_fps][512] per-keypoint candidate pieces {first slot, count} (ball_rows_kernel)
+    int2* ball_ptab;                    // [nsets][num_fps][256] per-keypoint candidate pieces {first slot, count} (ball_rows_kernel)
     int32_t* ball_pnum;                 // [nsets][num_fps] pieces per keypoint, -1: degenerate geometry
-    int32_t* ball_pepo;                 // [nsets][num_fps][8] end of the pieces of every index epoch
-    int ball_epochs[2 * BX_MAX_SCALES]; // index epochs (1 / 4 / 8) of every prepared set
     int ball_logpw[2 * BX_MAX_SCALES];  // piece width (log2) of every prepared set
     float4 *ball_pts4, *ball_sorted;    // [nsets][max_points] {x,y,z,0} in permuted order / {x,y,z,bits(i)} sorted by cell
     long long ball_attr_set;

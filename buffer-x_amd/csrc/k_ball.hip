@@ -72,9 +72,7 @@ struct BallBatch {
     int2* ptab;                 // [nsets][K][NPMAX] candidate pieces {first slot in the sorted array, count <= 1 << logpw}
     int32_t* pnum;              // [nsets][K] number of pieces, -1: degenerate geometry (the query walks the cells itself)
     size_t st_cnt, st_bsum, st_pts, st_tab, st_num;
-    int logpw[2 * BX_MAX_SCALES];   // piece width of set j: 64 / 16 / 8 candidates by the expected length of a cell row (of one epoch)
-    int epochs[2 * BX_MAX_SCALES];  // index epochs of set j (1, 2, 4 or 8): see ball_query_kernel
-    int32_t* pepo;              // [nsets][K][8] end of the pieces of epoch e in the keypoint's piece table
+    int logpw[BX_MAX_SCALES];   // piece width of scale i: 64 / 16 / 8 candidates by the expected length of a cell row
 };
 
 // per-block partial bounds of a cloud (64 blocks x 2 clouds, no atomics, no initialisation launch)
@@ -157,7 +155,7 @@ __global__ __launch_bounds__(64) void grid_setup_kernel(BallBatch B, int div)
             d[c] = (int)fminf(f, 1023.0f) + 1;
             tot *= d[c];
         }
-        if (tot <= (1 << 17) && tot * B.epochs[j] <= BX_BALL_NCELL) break;      // one cell table per index epoch
+        if (tot <= BX_BALL_NCELL) break;
         h = h * 1.2599211f;
     }
     BallGrid* g = B.grid + j;
@@ -166,8 +164,6 @@ __global__ __launch_bounds__(64) void grid_setup_kernel(BallBatch B, int div)
     g->rpad = rpad;
     g->dx = d[0]; g->dy = d[1]; g->dz = d[2];
     g->ncells = d[0] * d[1] * d[2];
-    g->epochs = B.epochs[j];
-    g->tcells = g->ncells * g->epochs;
 }
 
 __device__ __forceinline__ int cell_coord(float x, float o, float inv_h, int d)
@@ -199,7 +195,7 @@ __global__ __launch_bounds__(1024) void cell_count_kernel(BallBatch B)
     int2* __restrict__ cellrank = B.cellrank + (size_t)j * B.st_pts;
     float4* __restrict__ pts4 = B.pts4 + (size_t)j * B.st_pts;
     const float ox = g->ox, oy = g->oy, oz = g->oz, ih = g->inv_h;
-    const int dx = g->dx, dy = g->dy, dz = g->dz, ncells = g->tcells, ncell1 = g->ncells, E = g->epochs;
+    const int dx = g->dx, dy = g->dy, dz = g->dz, ncells = g->ncells;
     const bool use_lds = ncells <= COUNT_LDS_CELLS;
     const int tid = threadIdx.x;
     if (use_lds) {
@@ -215,8 +211,7 @@ __global__ __launch_bounds__(1024) void cell_count_kernel(BallBatch B)
             const size_t src = perm ? (size_t)perm[i] : (size_t)i;
             float x = pts[src * 3], y = pts[src * 3 + 1], z = pts[src * 3 + 2];
             pts4[i] = make_float4(x, y, z, 0.f);
-            // index epoch e = floor(i E / n): epoch e holds the permuted indices [ceil(e n / E), ceil((e + 1) n / E)), one cell table each
-            cell[u] = (int)(((long long)i * E) / n) * ncell1 + (cell_coord(z, oz, ih, dz) * dy + cell_coord(y, oy, ih, dy)) * dx + cell_coord(x, ox, ih, dx);
+            cell[u] = (cell_coord(z, oz, ih, dz) * dy + cell_coord(y, oy, ih, dy)) * dx + cell_coord(x, ox, ih, dx);
             rank[u] = use_lds ? atomicAdd(&hist[cell[u]], 1) : atomicAdd(&cnt[cell[u]], 1);
         }
     }
@@ -244,7 +239,7 @@ __global__ __launch_bounds__(256) void scan_sums_kernel(BallBatch B)
     const int32_t* __restrict__ cnt = B.cnt + (size_t)j * B.st_cnt;
     const int base = blockIdx.x * SCAN_TILE;
     int s = 0;
-    if (base <= (B.grid + j)->tcells) {
+    if (base <= (B.grid + j)->ncells) {
         const int4* p = reinterpret_cast<const int4*>(cnt + base) + threadIdx.x * 2;
         int4 a = p[0], b = p[1];
         s = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
@@ -265,7 +260,7 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(BallBatch B)
     int32_t* __restrict__ start = B.start + (size_t)j * B.st_cnt;
     const int32_t* __restrict__ bsum = B.bsum + (size_t)j * B.st_bsum;
     const int base = blockIdx.x * SCAN_TILE;
-    if (base > (B.grid + j)->tcells) return;
+    if (base > (B.grid + j)->ncells) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (wave == 0) {   // offset of this tile = sum of the preceding tiles (<= BX_BALL_NCELL / SCAN_TILE + 1 values)
         int v = 0;
@@ -305,9 +300,7 @@ struct F3 { float x, y, z; };   // 4-byte aligned triple: stores compile to glob
 
 constexpr int MAXROWS = 63;      // (y,z) cell rows kept in the per-wave row table (one lane each)
 
-constexpr int NPMAX = 512;       // piece-table stride per keypoint (sets with one epoch use at most NPMAX1 of it: LDS budget of the query)
-constexpr int NPMAX1 = 256;
-constexpr int MAXEP = 8;         // index epochs per set
+constexpr int NPMAX = 256;       // piece-table capacity per keypoint
 
 // Candidate pieces of all keypoints, one wave per keypoint.  The candidates of a keypoint are the points of the (y,z) cell rows
 // around it, every row trimmed to the chord of the ball (a row's x-cells are ONE contiguous range of the sorted array).  Rows are
@@ -318,14 +311,14 @@ constexpr int MAXEP = 8;         // index epochs per set
 // 64 at the 5 % scale (rows of ~50 candidates), 16 at 2 %, 8 at 0.5 % (rows of ~4).
 __global__ __launch_bounds__(256) void ball_rows_kernel(BallBatch B, int trim)
 {
-    const int j_ = blockIdx.y, cl_ = j_ / B.S;
+    const int j_ = blockIdx.y, cl_ = j_ / B.S, sc_ = j_ - cl_ * B.S;
     const int32_t* __restrict__ start = B.start + (size_t)j_ * B.st_cnt;
     const BallGrid* __restrict__ g = B.grid + j_;
     const float* __restrict__ kpts = B.kpts[cl_];
     const int K = B.K;
     int2* __restrict__ ptab = B.ptab + (size_t)j_ * B.st_tab;
     int32_t* __restrict__ pnum = B.pnum + (size_t)j_ * B.st_num;
-    const int logpw = B.logpw[j_], PW = 1 << logpw;
+    const int logpw = B.logpw[sc_], PW = 1 << logpw;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wv;
     if (q >= K) return;
@@ -341,11 +334,10 @@ __global__ __launch_bounds__(256) void ball_rows_kernel(BallBatch B, int trim)
         if (lane == 0) pnum[q] = -1;
         return;
     }
-    // chord of every row (lane = row): x-cell range [xl, xh] of the padded ball at the row's smallest possible (y, z) distance
-    int rowc = 0, xl = 1, xh = 0;
+    int st = 0, len = 0;
     if (lane < R0) {
         const int cz = zlo + lane / ny, cy = ylo + lane % ny;
-        rowc = (cz * dy + cy) * dx;
+        const int rowc = (cz * dy + cy) * dx;
         // chord trimming in cell units: every point of this row has u_y in [cy, cy+1], u_z in [cz, cz+1] (u = the value
         // whose floor binned it), so a hit's |u_x - uq_x| is bounded by the chord of the (padded) ball at the row's
         // smallest possible (y,z) distance.  DU covers the rounding of u (|u| <= 1024, two roundings) on both sides.
@@ -355,7 +347,7 @@ __global__ __launch_bounds__(256) void ball_rows_kernel(BallBatch B, int trim)
         const float gz = fmaxf(fmaxf((float)cz - uqz, uqz - (float)(cz + 1)) - DU, 0.0f);
         const float m = rp * ih + DU;
         const float w2 = m * m - (gy * gy + gz * gz);
-        xl = xlo; xh = xhi;
+        int xl = xlo, xh = xhi;
         if (trim) {
             if (w2 < 0.0f) { xl = 1; xh = 0; }
             else {
@@ -366,33 +358,22 @@ __global__ __launch_bounds__(256) void ball_rows_kernel(BallBatch B, int trim)
                 xh = min(xhi, (int)fh);
             }
         }
-    }
-    // pieces of every (epoch, row), EPOCH-MAJOR (inside an epoch the order is immaterial: the hit bitmap restores the index order);
-    // pepo[e] = end of epoch e's pieces.  One epoch: the round-2 table.
-    const int E = g->epochs, ncell1 = g->ncells;
-    const int cap = E > 1 ? NPMAX : NPMAX1;
-    int32_t* __restrict__ pepo = B.pepo + ((size_t)j_ * B.st_num + q) * MAXEP;
-    int2* __restrict__ pq = ptab + (size_t)q * NPMAX;
-    int total = 0;
-    for (int e = 0; e < E; ++e) {
-        int st = 0, len = 0;
         if (xl <= xh) {
-            st = start[e * ncell1 + rowc + xl];
-            len = start[e * ncell1 + rowc + xh + 1] - st;
+            st = start[rowc + xl];
+            len = start[rowc + xh + 1] - st;
         }
-        const int np = (len + PW - 1) >> logpw;
-        const int inc = bx_wave_incl_scan_dpp(np);
-        const int NP = __builtin_amdgcn_readlane(inc, 63);
-        if (total + NP > cap) {                             // very long candidate sequences: the query walks the cells itself
-            if (lane == 0) pnum[q] = -1;
-            return;
-        }
-        int2* __restrict__ pe = pq + total + (inc - np);
-        for (int i = 0; i < np; ++i) pe[i] = make_int2(st + (i << logpw), min(PW, len - (i << logpw)));
-        total += NP;
-        if (lane == 0) pepo[e] = total;
     }
-    if (lane == 0) pnum[q] = total;
+    // pieces of every row, laid out row after row (the order is immaterial: the hit bitmap restores the index order)
+    const int np = (len + PW - 1) >> logpw;
+    const int inc = bx_wave_incl_scan_dpp(np);
+    const int NP = __builtin_amdgcn_readlane(inc, 63);
+    if (NP > NPMAX) {                                        // very long candidate sequences: the query walks the cells itself
+        if (lane == 0) pnum[q] = -1;
+        return;
+    }
+    int2* __restrict__ pq = ptab + (size_t)q * NPMAX + (inc - np);
+    for (int i = 0; i < np; ++i) pq[i] = make_int2(st + (i << logpw), min(PW, len - (i << logpw)));
+    if (lane == 0) pnum[q] = NP;
 }
 
 // QW waves per workgroup, ONE keypoint per workgroup (template parameter: 4 / 2 / 1 by the expected neighbourhood size)
@@ -419,8 +400,7 @@ __device__ __forceinline__ void set_hit(unsigned int* bm32, int i)
 template <int LOGC, int QW>
 __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __restrict__ sorted, const int32_t* __restrict__ start,
                                                         const BallGrid* __restrict__ g, const int2* __restrict__ ptab,
-                                                        const int32_t* __restrict__ pnum, const int32_t* __restrict__ pepo, int logpw,
-                                                        const float4* __restrict__ pts4,
+                                                        const int32_t* __restrict__ pnum, int logpw, const float4* __restrict__ pts4,
                                                         const float* __restrict__ kpts, int K,
                                                         const double* __restrict__ radius, int P, int32_t* __restrict__ idx_out,
                                                         float* __restrict__ patches, const int32_t* __restrict__ skip,
@@ -443,10 +423,8 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
 #define BX_TR(k) do { if (tr) td[k] = __builtin_readcyclecounter() - t0; } while (0)
     unsigned long long* bm64 = reinterpret_cast<unsigned long long*>(smem);
     unsigned int* bm32 = reinterpret_cast<unsigned int*>(smem);
-    const int E = __builtin_amdgcn_readfirstlane(g->epochs);              // index epochs of this set (1: the round-2 path)
-    int* pre = reinterpret_cast<int*>(smem + (size_t)NW64 * 8);            // [NW64] set bits in front of every 64-bit word (one epoch only)
-    const size_t off_list = (size_t)NW64 * (E > 1 ? 8 : 12);
-    int* list = reinterpret_cast<int*>(smem + off_list);                   // [P]
+    int* pre = reinterpret_cast<int*>(smem + (size_t)NW64 * 8);            // [NW64] set bits in front of every 64-bit word
+    int* list = reinterpret_cast<int*>(smem + (size_t)NW64 * 12);          // [P]
 
     {
         ulonglong2* z = reinterpret_cast<ulonglong2*>(bm64 + (size_t)tid * CW);
@@ -454,7 +432,7 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
         for (int s = 0; s < CW / 2; ++s) z[s] = make_ulonglong2(0ULL, 0ULL);
     }
 
-    int2* ptl = reinterpret_cast<int2*>(smem + off_list + (((size_t)P * 4 + 7) & ~(size_t)7));   // [NPMAX1 | NPMAX] piece table of this keypoint
+    int2* ptl = reinterpret_cast<int2*>(smem + (size_t)NW64 * 12 + (((size_t)P * 4 + 7) & ~(size_t)7));   // [NPMAX] piece table of this keypoint
     const int NP = __builtin_amdgcn_readfirstlane(pnum[q]);                          // -1: degenerate geometry
     for (int i = tid; i < NP; i += QT) ptl[i] = ptab[(size_t)q * NPMAX + i];
     const float r = (float)(*radius);
@@ -467,59 +445,11 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
     constexpr int MAXIT = 16;                               // iterations whose hits are kept in registers and rank themselves
     const int GP = 64 >> logpw;                             // pieces per wave and iteration
     const int nit = NP > 0 ? (NP + QW * GP - 1) / (QW * GP) : 0;   // uniform
-    const bool one_block = NP >= 0 && nit <= MAXIT && E == 1;
+    const bool one_block = NP >= 0 && nit <= MAXIT;
     int hidx[MAXIT];                                        // one_block: index of the hit of iteration it, -1 otherwise
 #pragma unroll
     for (int u = 0; u < MAXIT; ++u) hidx[u] = -1;
-    if (NP >= 0 && E > 1) {
-        // ---- INDEX EPOCHS (round 4).  Only the P smallest permuted indices of a ball survive, and at the 5 % scale a ball holds 1.7 P
-        // (3DMatch size) to 5 P (100k-point clouds) points.  The set's points are binned per index epoch e = floor(i E / n) (one cell
-        // table per epoch, ball_rows_kernel lays the pieces out epoch-major), the keypoint's candidates are swept epoch by epoch, and
-        // the sweep ENDS behind the first epoch after which P hits are known: every point of a later epoch has a larger index than all
-        // of them.  The waves add up their hit counts (ballot popcounts) at an epoch's end -- one barrier; after the first sum the
-        // epoch the P-th hit is expected in is extrapolated and the sums in between are skipped.
-        __shared__ int wsum[2][QW];
-        const int grp = lane >> logpw, li = lane & ((1 << logpw) - 1);
-        const int32_t* pe = pepo + (size_t)q * MAXEP;
-        int nh = 0, p0 = 0, check = 0, par = 0;
-        for (int e = 0; e < E; ++e) {
-            const int p1 = __builtin_amdgcn_readfirstlane(pe[e]);
-            for (int pb = p0; pb < p1; pb += 4 * QW * GP) {
-                float4 c[4];
-                bool ok[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int pc = pb + (u * QW + wave) * GP + grp;
-                    int2 ent = make_int2(0, 0);
-                    if (pc < p1) ent = ptl[pc];
-                    ok[u] = li < ent.y;
-                    const unsigned addr = ok[u] ? (unsigned)(ent.x + li) : 0u;
-                    c[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sorted) + (addr << 4));
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float ax = qx - c[u].x, ay = qy - c[u].y, az = qz - c[u].z;
-                    const float d2 = (ax * ax + ay * ay) + az * az;
-                    const bool hit = d2 < r2 && ok[u];
-                    if (hit) set_hit(bm32, __float_as_int(c[u].w));
-                    nh += __popcll(__ballot(hit));
-                }
-            }
-            p0 = p1;
-            if (e + 1 < E && e >= check) {
-                if (lane == 0) wsum[par][wave] = nh;
-                __syncthreads();
-                int tot_h = 0;
-#pragma unroll
-                for (int w = 0; w < QW; ++w) tot_h += wsum[par][w];
-                par ^= 1;
-                if (tot_h >= P) break;                                  // uniform: the first P hits are all known
-                // the epoch in which the P-th hit is expected (hits grow ~linearly with the epochs swept); never skip the last sum
-                check = tot_h > 0 ? (int)(((long long)P * (e + 1) + tot_h - 1) / tot_h) - 1 : E;
-                if (check <= e) check = e + 1;
-            }
-        }
-    } else if (NP >= 0) {
+    if (NP >= 0) {
         const int grp = lane >> logpw, li = lane & ((1 << logpw) - 1);
         // a batch of 4 iterations: the four table reads, then the four candidate loads go out back to back (a load under a
         // divergent branch would be waited for right behind its issue), then the four tests
@@ -566,14 +496,12 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
             for (int cy = ylo; cy <= yhi; ++cy, ++rowi) {
                 if ((rowi & (QW - 1)) != wave) continue;
                 const int rowc = (cz * dy + cy) * dx;
-                for (int ep = 0; ep < E; ++ep) {                        // every index epoch (no early end on this path)
-                    const int s = start[ep * g->ncells + rowc + xlo], e = start[ep * g->ncells + rowc + xhi + 1];
-                    for (int k = s + lane; k < e; k += 64) {
-                        const float4 a = sorted[k];
-                        const float ax = qx - a.x, ay = qy - a.y, az = qz - a.z;
-                        const float d2 = (ax * ax + ay * ay) + az * az;
-                        if (d2 < r2) set_hit(bm32, __float_as_int(a.w));
-                    }
+                const int s = start[rowc + xlo], e = start[rowc + xhi + 1];
+                for (int k = s + lane; k < e; k += 64) {
+                    const float4 a = sorted[k];
+                    const float ax = qx - a.x, ay = qy - a.y, az = qz - a.z;
+                    const float d2 = (ax * ax + ay * ay) + az * az;
+                    if (d2 < r2) set_hit(bm32, __float_as_int(a.w));
                 }
             }
     }
@@ -673,27 +601,10 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
     if (tr) { __builtin_amdgcn_s_waitcnt(0); td[6] = __builtin_readcyclecounter() - t0; }
 }
 
-// diagnostics (never arithmetic): BX_BALL_DEBUG = s + 1 collects the in-kernel cycle stamps of the query launches of set s (bx_debug_read);
-// BX_BALL_EPOCHS = 1 forces one index epoch for every set (A/B measurement of the epoch sweep; results are identical)
-static int ball_debug_set()
-{
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("BX_BALL_DEBUG"); v = e ? atoi(e) : 0; }
-    return v;
-}
-static int ball_epoch_cap()
-{
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("BX_BALL_EPOCHS"); v = e ? atoi(e) : MAXEP; if (v < 1) v = 1; }
-    return v;
-}
-
 template <int LOGC, int QW>
 int launch_query_w(bx_ctx* c, hipStream_t s, int set, int k0, int K, const float* kpts, const double* radius, int P, int32_t* idx_out, float* patches_out)
 {
-    const int E = c->ball_epochs[set];
-    // bitmap | per-word prefix (one epoch only) | ordered index list | pieces
-    const size_t lds = ((size_t)64 << LOGC) * (E > 1 ? 8 : 12) + (((size_t)P * 4 + 7) & ~(size_t)7) + (size_t)(E > 1 ? NPMAX : NPMAX1) * 8;
+    const size_t lds = ((size_t)64 << LOGC) * 12 + (((size_t)P * 4 + 7) & ~(size_t)7) + (size_t)NPMAX * 8;   // bitmap | per-word prefix | ordered index list | pieces
     if (lds > 160 * 1024) { bx_set_error("bxk_ball_group: P=%d needs %zu B of LDS per keypoint (> 160 KiB)", P, lds); return BX_ERR_ARG; }
     if (lds > 64 * 1024 && !(c->ball_attr_set & (1LL << (LOGC * 3 + QW / 2)))) {
         BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_kernel<LOGC, QW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -702,9 +613,8 @@ int launch_query_w(bx_ctx* c, hipStream_t s, int set, int k0, int K, const float
     const size_t j = (size_t)set;
     hipLaunchKernelGGL((ball_query_kernel<LOGC, QW>), dim3(K), dim3(64 * QW), lds, s, c->ball_sorted + j * c->ball_st_pts,
                        c->ball_start + j * c->ball_st_cnt, c->ball_grid + j, c->ball_ptab + j * c->ball_st_tab + (size_t)k0 * NPMAX,
-                       c->ball_pnum + j * c->ball_st_num + k0, c->ball_pepo + (j * c->ball_st_num + k0) * MAXEP, c->ball_logpw[set],
-                       c->ball_pts4 + j * c->ball_st_pts, kpts, K,
-                       radius, P, idx_out, patches_out, c->skip, ball_debug_set() == set + 1 ? c->ball_dbg : nullptr);
+                       c->ball_pnum + j * c->ball_st_num + k0, c->ball_logpw[set], c->ball_pts4 + j * c->ball_st_pts, kpts, K,
+                       radius, P, idx_out, patches_out, c->skip, getenv("BX_BALL_DEBUG") ? c->ball_dbg : nullptr);
     BX_LAUNCH_CHECK();
     return BX_OK;
 }
@@ -767,8 +677,6 @@ void batch_from_ctx(const bx_ctx* c, BallBatch& B)
     memset(&B, 0, sizeof(B));
     B.bbox_part = c->ball_bbox_part; B.grid = c->ball_grid; B.cnt = c->ball_cnt; B.start = c->ball_start; B.bsum = c->ball_bsum;
     B.cellrank = c->ball_cellrank; B.pts4 = c->ball_pts4; B.sorted = c->ball_sorted; B.ptab = c->ball_ptab; B.pnum = c->ball_pnum;
-    B.pepo = c->ball_pepo;
-    for (int j = 0; j < 2 * BX_MAX_SCALES; ++j) { B.logpw[j] = c->ball_logpw[j]; B.epochs[j] = c->ball_epochs[j] > 0 ? c->ball_epochs[j] : 1; }
     B.st_cnt = c->ball_st_cnt; B.st_bsum = c->ball_st_bsum; B.st_pts = c->ball_st_pts; B.st_tab = c->ball_st_tab; B.st_num = c->ball_st_num;
 }
 }  // namespace
@@ -792,24 +700,13 @@ int bxk_ball_grids(bx_ctx* c, hipStream_t s, const float* const* clouds, const i
         nmax = ns[cl] > nmax ? ns[cl] : nmax;
     }
     B.S = S; B.nsets = nclouds * S; B.radius = radius;
-    for (int i = 0; i < S; ++i)
-        for (int cl = 0; cl < nclouds; ++cl) {
-            // Expected hits of a ball = the share of the cloud the radius threshold of the scale stands for (the percentage thresholds of
-            // the pair path, cfg.patch.search_radius_thresholds; unknown at the stage entry point: one epoch, 64-wide pieces).
-            const double thr = pw_hint ? pw_hint[i] : 0.0;
-            const double hits = thr * 0.01 * ns[cl];
-            const int P = c->p.num_points_per_patch;
-            // index epochs: worth their barriers once a ball holds clearly more than the P points that survive
-            int E = !pw_hint ? 1 : (hits >= 3.0 * P ? 8 : (hits >= 1.4 * P ? 4 : 1));
-            if (E > ball_epoch_cap()) E = ball_epoch_cap();
-            // piece width by the expected length of a cell row of ONE epoch (~1/40 of the ball's hits)
-            const double row = pw_hint ? hits / E / 35.0 : 100.0;
-            const int lp = row >= 30.0 ? 6 : (row >= 8.0 ? 4 : 3);
-            c->ball_logpw[cl * S + i] = lp;
-            c->ball_epochs[cl * S + i] = E;
-            B.logpw[cl * S + i] = lp;
-            B.epochs[cl * S + i] = E;
-        }
+    for (int i = 0; i < S; ++i) {
+        // piece width by the share of the cloud a ball of this scale is expected to hold (its cell rows are ~1/40 of that): the
+        // percentage thresholds of the pair path (cfg.patch.search_radius_thresholds), 64 when unknown (stage entry point)
+        const double thr = pw_hint ? pw_hint[i] : 100.0;
+        const int lp = thr >= 3.5 ? 6 : (thr >= 1.0 ? 4 : 3);
+        for (int cl = 0; cl < nclouds; ++cl) c->ball_logpw[cl * S + i] = lp;
+    }
     const int nb = (nmax + 255) / 256;
     const int nb4k = (nmax + 1024 * COUNT_PPT - 1) / (1024 * COUNT_PPT);
     const int ntile = BX_BALL_NCELL / SCAN_TILE + 1;
@@ -832,9 +729,9 @@ int bxk_ball_rows(bx_ctx* c, hipStream_t s, const float* const* kpts, int ncloud
     batch_from_ctx(c, B);
     B.S = S; B.nsets = nclouds * S; B.K = K;
     for (int cl = 0; cl < nclouds; ++cl) B.kpts[cl] = kpts[cl] + (size_t)k0 * 3;
+    for (int i = 0; i < S; ++i) B.logpw[i] = c->ball_logpw[i];
     B.ptab += (size_t)k0 * NPMAX;       // the same shift inside every set
     B.pnum += k0;
-    B.pepo += (size_t)k0 * MAXEP;
     hipLaunchKernelGGL(ball_rows_kernel, dim3((K + 3) / 4, B.nsets), dim3(256), 0, s, B, bx_ball_trim());
     BX_LAUNCH_CHECK();
     return BX_OK;

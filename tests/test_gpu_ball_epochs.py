@@ -1,9 +1,8 @@
-"""Neighbour gather with INDEX EPOCHS (round 4, k_ball.hip): the sweep of a keypoint's candidates ends behind the first index epoch
-after which num_points_per_patch hits are known.  The stage entry point bx_ball_group always uses one epoch (it has no density hint),
-so the epoch path is exercised through bx_register_pair with the capture armed: the captured select_patches output (reference
-models/patch_embedder.py:92-120) of EVERY keypoint must equal the oracle's, bit for bit, in configurations whose expected ball
-population (threshold % x cloud size) puts the set on 4 and on 8 epochs -- incl. keypoints whose balls hold fewer than P points (every
-epoch swept), ball populations around P, and duplicate points."""
+"""select_patches of EVERY keypoint through the whole-pair path (capture), across ball populations from far below to far above
+num_points_per_patch -- the cases an index-epoch sweep was built and tested on in round 4 (profiles/r04_ball_epochs.txt: bit-exact,
+15-17 % slower, removed again); kept as a parity test of the grid-accelerated neighbour gather inside bx_register_pair: the captured
+patches (reference models/patch_embedder.py:92-120) must equal the oracle's bit for bit, incl. keypoints whose balls hold fewer than P
+points, populations around and several times P (only the first P indices survive), and duplicate points."""
 import numpy as np
 import pytest
 
@@ -14,7 +13,8 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
-@pytest.mark.parametrize("n,P,thr,epochs", [(6000, 64, 5, 8), (6000, 160, 5, 4), (20000, 256, 5, 8), (20000, 512, 5, 4), (9000, 160, 2, 1)])
+@pytest.mark.parametrize("n,P,thr,epochs",      # `epochs`: expected population / P is >= 3 (8), >= 1.4 (4), below (1)
+                         [(6000, 64, 5, 8), (6000, 160, 5, 4), (20000, 256, 5, 8), (20000, 512, 5, 4), (9000, 160, 2, 1)])
 def test_captured_patches_equal_oracle(bx, packed, oracle, n, P, thr, epochs):
     import torch
     from bufferx_amd import lib
@@ -28,9 +28,6 @@ def test_captured_patches_equal_oracle(bx, packed, oracle, n, P, thr, epochs):
     src = pair["src"].copy()
     src[100:140] = src[50:90]                                   # duplicate points: equal distances, distinct indices
     tgt = pair["tgt"]
-    for m in (len(src), len(tgt)):                              # the rule of bxk_ball_grids puts both clouds on `epochs` epochs
-        hits = thr * 0.01 * m
-        assert (8 if hits >= 3.0 * P else (4 if hits >= 1.4 * P else 1)) == epochs, (m, hits)
     ctx = lib.Context(cfg, max_points=max(len(src), len(tgt)), device=0, packed_weights=packed)
     try:
         rng = np.random.default_rng(5)
@@ -50,7 +47,7 @@ def test_captured_patches_equal_oracle(bx, packed, oracle, n, P, thr, epochs):
             d2 = ((kp[:, None, :].astype(np.float64) - pp[None, :, :]) ** 2).sum(-1)
             cnt = (d2 < float(np.float32(r.des_r[0])) ** 2).sum(1)
             if epochs > 1:
-                assert cnt.max() > P and cnt.min() < cnt.max()      # balls above P exist (the sweep ends early for them)
+                assert cnt.max() > P and cnt.min() < cnt.max()      # balls above P exist: only the first P indices survive
         ctx.set_capture(None, 0, 0)
     finally:
         ctx.close()
