@@ -149,7 +149,7 @@ def main():
     ap.add_argument("--lane", type=int, default=0, help="bx_lane mode ordering the pairs in flight: 0 none, 1 whole main phase, 2 conv stacks")
     ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic pairs (cycled; the same list on every rank); N of every cloud is drawn from U[20k, 60k]")
     ap.add_argument("--desc-conv", default=None, choices=["winograd43", "winograd22", "direct"], help="bx_params.desc_conv_form (default: the library default)")
-    ap.add_argument("--pose-conv", default=None, choices=["winograd", "direct"], help="bx_params.pose_conv_form")
+    ap.add_argument("--pose-conv", default=None, choices=["winograd43", "winograd22", "direct"], help="bx_params.pose_conv_form")
     ap.add_argument("--cost-l0", default=None, choices=["collapsed", "direct"], help="bx_params.cost_l0_form")
     ap.add_argument("--inflight-sweep", default="1,2,4,8", help="pairs in flight of the throughput-vs-latency sweep after the timed region ('' = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -399,12 +399,14 @@ def main():
             alg = COSTNET_MMAC_PER_MATCH if direct0 else COSTNET_MMAC_PER_MATCH - COSTNET_L0_MMAC + COSTNET_L0_COLLAPSED_MMAC
             # issued on the f32 matrix pipe: layers 1..5 as Winograd F(2x2,3x3) (16 planes x padded tile rows), layers 6..9 direct;
             # the collapsed layer 0 is binary64 VALU work
-            ex = (27.263 + 1.661 if wino_p else 53.124) + (COSTNET_L0_MMAC if direct0 else 0.0)
+            # (valid F(4x4,3x3): 36 planes x 32 tile rows per G = 2 / 2 / 3 / 3 / 8 units and layer = 16.515 MMAC per match; F(2x2,3x3): 27.263)
+            ex = {"winograd43": 16.515 + 1.661, "winograd22": 27.263 + 1.661, "direct": 53.124}[forms["pose_conv"]] + (COSTNET_L0_MMAC if direct0 else 0.0)
             fl = 2.0 * alg * 1e6 * mean_m
             ach = fl / (pose_ms / pose_n * 1e-3) / 1e12
             ex_ach = 2.0 * ex * 1e6 * mean_m / (pose_ms / pose_n * 1e-3) / 1e12
             roof_cn = {"kernel": ("cost_l1_kernel" if direct0 else "cost_l0_kernel (collapsed layer 0, binary64 VALU)") +
-                                 (" + wino_pose_kernel x5 (Winograd F(2x2,3x3)) + conv_kernel x4" if wino_p else " + conv_kernel x9") + " + soft_argmax (CostNet)",
+                                 ({"winograd43": " + wino43v_kernel x5 (valid Winograd F(4x4,3x3)) + conv_kernel x4", "winograd22": " + wino_pose_kernel x5 (Winograd F(2x2,3x3)) + conv_kernel x4",
+                                   "direct": " + conv_kernel x9"}[forms["pose_conv"]]) + " + soft_argmax (CostNet)",
                        "bound": "mfma", "achieved": round(ex_ach, 3),
                        "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": round(ex_ach / PEAK_F32_MATRIX_TFLOPS, 4),
                        "frac_note": "flops ISSUED on the f32 matrix pipe (%.2f MMAC per match) over the time of the whole CostNet / peak" % ex,

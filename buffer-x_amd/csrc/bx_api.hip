@@ -387,7 +387,7 @@ static int create_impl(bx_ctx* c, int device_id)
         c->conv_cap_override = e ? atoi(e) : 0;
         // arithmetic forms: bx_params (validated by bx_create), never the environment
         c->use_wino = p.desc_conv_form == BX_DESC_CONV_DIRECT ? 0 : (p.desc_conv_form == BX_DESC_CONV_WINOGRAD22 ? 1 : 2);
-        c->use_wino_pose = p.pose_conv_form == BX_POSE_CONV_DIRECT ? 0 : 1;
+        c->use_wino_pose = p.pose_conv_form == BX_POSE_CONV_DIRECT ? 0 : (p.pose_conv_form == BX_POSE_CONV_WINOGRAD22 ? 1 : 2);
         c->cost_direct = p.cost_l0_form == BX_COST_L0_DIRECT ? 1 : 0;
     }
     (void)p;
@@ -516,7 +516,7 @@ int bx_destroy(bx_ctx* c)
     (void)hipFree(c->d_centres); (void)hipFree(c->d_rot); (void)hipFree(c->d_rowc); (void)hipFree(c->d_rad_thr);
     (void)hipFree(c->d_pnt_w); (void)hipFree(c->d_pnt_b); (void)hipFree(c->d_pool_w1); (void)hipFree(c->d_pool_b1); (void)hipFree(c->d_pool_w2); (void)hipFree(c->d_pool_b2);
     for (int i = 0; i < BX_NDESC; ++i) { (void)hipFree(c->desc[i].W); (void)hipFree(c->desc[i].Wwino); (void)hipFree(c->desc[i].Wwino43); (void)hipFree(c->desc[i].b); (void)hipFree(c->desc[i].lrow); (void)hipFree(c->desc[i].lrow2); (void)hipFree(c->desc[i].obase); (void)hipFree(c->desc[i].toff); }
-    for (int i = 0; i < BX_NPOSE; ++i) { (void)hipFree(c->pose[i].W); (void)hipFree(c->pose[i].Wwino); (void)hipFree(c->pose[i].b); (void)hipFree(c->pose[i].lrow); (void)hipFree(c->pose[i].lrow2); (void)hipFree(c->pose[i].obase); (void)hipFree(c->pose[i].toff); }
+    for (int i = 0; i < BX_NPOSE; ++i) { (void)hipFree(c->pose[i].W); (void)hipFree(c->pose[i].Wwino); (void)hipFree(c->pose[i].Wwino43); (void)hipFree(c->pose[i].b); (void)hipFree(c->pose[i].lrow); (void)hipFree(c->pose[i].lrow2); (void)hipFree(c->pose[i].obase); (void)hipFree(c->pose[i].toff); }
     delete c;
     return BX_OK;
 }
@@ -627,7 +627,7 @@ int bx_load_weights(bx_ctx* c, const bx_weights* w)
         L.nchunk = dc[l][0]; L.ntaps = 9; L.p_in = BX_EA; L.p_out = BX_EA; L.cout = dc[l][1]; L.relu = l < BX_NDESC - 1;
         if ((rc = upload_w(L, w->desc_w[l])) != BX_OK) return rc;
         if (c->use_wino == 1 && L.cout >= 64 && (rc = bxk_wino_weights(w->desc_w[l], L.nchunk, 1, L.cout, &L.Wwino)) != BX_OK) return rc;
-        if (c->use_wino == 2 && (rc = bxk_wino43_weights(w->desc_w[l], L.nchunk, L.cout, &L.Wwino43)) != BX_OK) return rc;
+        if (c->use_wino == 2 && (rc = bxk_wino43_weights(w->desc_w[l], L.nchunk, 1, L.cout, &L.Wwino43)) != BX_OK) return rc;
         if ((rc = upload(&L.b, w->desc_b[l], (size_t)L.cout)) != BX_OK) return rc;
         if ((rc = upload_geo(L, cg)) != BX_OK) return rc;
     }
@@ -645,7 +645,8 @@ int bx_load_weights(bx_ctx* c, const bx_weights* w)
         if ((rc = upload_w(L, w->pose_w[l])) != BX_OK) return rc;
         if ((rc = upload(&L.b, w->pose_b[l], (size_t)L.cout)) != BX_OK) return rc;
         if ((rc = upload_geo(L, vg)) != BX_OK) return rc;
-        if (c->use_wino_pose && l >= 1 && l <= 5 && (rc = bxk_wino_weights(w->pose_w[l], L.nchunk, k[1], L.cout, &L.Wwino)) != BX_OK) return rc;
+        if (c->use_wino_pose == 1 && l >= 1 && l <= 5 && (rc = bxk_wino_weights(w->pose_w[l], L.nchunk, k[1], L.cout, &L.Wwino)) != BX_OK) return rc;
+        if (c->use_wino_pose == 2 && l >= 1 && l <= 5 && (rc = bxk_wino43_weights(w->pose_w[l], L.nchunk, k[1], L.cout, &L.Wwino43)) != BX_OK) return rc;
         for (int i = 0; i < 3; ++i) dims[i] = o[i];
     }
     if ((rc = bxk_cost_l0_weights(w->pose_w[0], &c->d_cost_wp, &c->d_cost_wq)) != BX_OK) return rc;

@@ -181,8 +181,9 @@ struct bx_ctx {
     void* pre;                          // bx_pre_ws* (k_pre.hip): workspace of the pre-processing entry points, reserved on demand
     int conv_cap[2][BX_NPOSE];          // persistent-grid size of every conv layer on THIS device (0 = not set up yet)
     int wino_cap[BX_NDESC];             // the same for the Winograd kernels (k_wino.hip)
+    int wino43v_cap[BX_NPOSE];          // persistent grid of the valid F(4x4) kernels (k_wino43v.hip)
     int wino_pose_cap[BX_NPOSE];
-    int use_wino_pose;                  // bx_params.pose_conv_form == winograd: CostNet layers 1..5 as valid Winograd convolutions
+    int use_wino_pose;                  // bx_params.pose_conv_form: 1 = winograd (valid F(2x2, 3x3), k_wino.hip), 2 = winograd43 (valid F(4x4, 3x3), k_wino43v.hip), 0 = direct -- CostNet layers 1..5
     int use_wino;                       // bx_params.desc_conv_form: 2 = winograd43 (F(4x4, 3x3), every layer), 1 = winograd22 (F(2x2, 3x3), layers with >= 64 output channels), 0 = direct
     int conv_persist, conv_cap_override, n_cu;
     double *d_cost_wp, *d_cost_wq;      // collapsed CostNet layer 0 (k_cost.hip): binary64 weights of the P / Q convolutions
@@ -221,7 +222,8 @@ int bxk_patch_features(bx_ctx* c, hipStream_t s, const float* patches, int K, in
                        float* R_out, float* feat_out);
 int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, const int32_t* units_dev, int max_units,
              float* out);
-int bxk_wino43_weights(const float* w, int nchunk, int cout, float** d_out);
+int bxk_wino43_weights(const float* w, int nchunk, int fold, int cout, float** d_out);
+int bxk_wino43v(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t* units_dev, int max_units, float* out);
 int bxk_wino43(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t* units_dev, int max_units, float* out);
 int bxk_wino(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t* units_dev, int max_units, float* out);
 int bxk_wino_weights(const float* w, int nchunk, int fold, int cout, float** d_out);

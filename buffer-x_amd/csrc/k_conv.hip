@@ -584,8 +584,11 @@ int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, cons
             case 7: return launch_conv<2, 9, 140, CYL, 140, 32, 2, false>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
         }
     } else if (net == 1) {
-        if (c->use_wino_pose) {
-            const int rcw = bxk_wino_pose(c, s, layer, in, units_dev, max_units, out);
+        if (c->use_wino_pose == 2) {
+            const int rcw = bxk_wino43v(c, s, layer, in, units_dev, max_units, out);      // layers 1..5: valid F(4x4, 3x3)
+            if (rcw >= 0) return rcw;
+        } else if (c->use_wino_pose == 1) {
+            const int rcw = bxk_wino_pose(c, s, layer, in, units_dev, max_units, out);    // layers 1..5: valid F(2x2, 3x3)
             if (rcw >= 0) return rcw;
         }
         const ConvLayerDev& L = c->pose[layer];

@@ -30,7 +30,7 @@
 // Measured and NOT kept: the window straight from global memory (36 dword loads per thread: the texture addresser needs ~16 cycles per
 // wave-instruction of four 64-byte segments -- 1 800-4 700 cycles of blocked issue per chunk), a start stagger of the workgroups (no
 // change: the output phase is not a chip-wide burst), temporal output stores (no change).
-#include "bx_common.h"
+#include "wino43_common.h"
 #include <cstdlib>
 #include <vector>
 
@@ -39,92 +39,15 @@
 #endif
 
 namespace {
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int ROWF = 20;                         // floats per LDS row (16 + 4 pad)
+using namespace w43;
 constexpr int WP = BX_AZI + 2;                   // slab columns (wrap-around halo)
 constexpr int HP = BX_ELE + 3;                   // slab rows h = -1 .. 8 (tile row 1 reaches two rows below the map)
 constexpr int TR4 = (BX_ELE + 3) / 4, TC4 = BX_AZI / 4, NT4 = TR4 * TC4;   // 2 x 5 = 10 tiles
-constexpr int G4 = 3, ROWS4 = G4 * NT4, RT4 = (ROWS4 + 15) / 16, VR4 = RT4 * 16, VPL4 = VR4 * ROWF;   // 30 tile rows -> 32
-constexpr int NPL = 36, NPH = 18;                // planes, planes per wave half
+constexpr int G4 = 3, ROWS4 = G4 * NT4;          // three units = 30 tile rows of the 32
 constexpr int RP3 = WP * ROWF + 4, UP3 = HP * RP3;                         // slab row / unit pitch in floats: 444, 4 440
 constexpr size_t W43_LDS = (size_t)(G4 * UP3 + NPL * VPL4) * 4;            // 53 280 + 92 160 B
-constexpr int CT = 512;
 static_assert(NPH % 3 == 0 && BX_AZI % 4 == 0 && W43_LDS <= 160 * 1024 && (RP3 * 4) % 16 == 0 && 8 * 8 * 64 * 16 <= NPL * VPL4 * 4,
               "geometry, LDS, 16-byte slab rows, output exchange inside the V planes");
-
-// the six results of B^T on a 6-vector (contract: bxo_conv_wino43; t3 / t4 as fmaf(+-2, d3 - d1, c): 2 x is exact, so the rounding is
-// that of c +- e)
-__device__ __forceinline__ void bt6s(float d0, float d1, float d2, float d3, float d4, float d5, float (&o)[6])
-{
-    o[0] = fmaf(4.0f, d0, fmaf(-5.0f, d2, d4));
-    const float a = fmaf(-4.0f, d2, d4), b = fmaf(-4.0f, d1, d3);
-    o[1] = a + b;
-    o[2] = a - b;
-    const float c = d4 - d2, s = d3 - d1;
-    o[3] = fmaf(2.0f, s, c);
-    o[4] = fmaf(-2.0f, s, c);
-    o[5] = fmaf(4.0f, d1, fmaf(-5.0f, d3, d5));
-}
-
-template <int HALF>
-__device__ __forceinline__ void wino43_send(const f32x4 (&acc)[NPH][RT4], int rt, float (&ua)[4][4], float (&ub)[4][4], float (&uc)[4][4], float4* mine)
-{
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float rr[3][4];
-#pragma unroll
-        for (int x = 0; x < 3; ++x) {
-            const float m0 = acc[x * 6 + 0][rt][r], m1 = acc[x * 6 + 1][rt][r], m2 = acc[x * 6 + 2][rt][r], m3 = acc[x * 6 + 3][rt][r],
-                        m4 = acc[x * 6 + 4][rt][r], m5 = acc[x * 6 + 5][rt][r];
-            const float p = m1 + m2, q = m1 - m2, s = m3 + m4, t = m3 - m4;
-            rr[x][0] = (m0 + p) + s;
-            rr[x][1] = fmaf(2.0f, t, q);
-            rr[x][2] = fmaf(4.0f, s, p);
-            rr[x][3] = fmaf(8.0f, t, q) + m5;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (HALF == 0) { ua[r][j] = rr[0][j]; ub[r][j] = rr[1][j] + rr[2][j]; uc[r][j] = rr[1][j] - rr[2][j]; }
-            else           { ua[r][j] = rr[0][j] + rr[1][j]; ub[r][j] = rr[0][j] - rr[1][j]; uc[r][j] = rr[2][j]; }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (HALF == 0) {                                    // P_0[2] = r_1 + r_2, P_0[3] = r_1 - r_2
-            mine[(2 * j) * 64] = make_float4(ub[0][j], ub[1][j], ub[2][j], ub[3][j]);
-            mine[(2 * j + 1) * 64] = make_float4(uc[0][j], uc[1][j], uc[2][j], uc[3][j]);
-        } else {                                            // P_1[0] = r_3 + r_4, P_1[1] = 2 (r_3 - r_4)
-            mine[(2 * j) * 64] = make_float4(ua[0][j], ua[1][j], ua[2][j], ua[3][j]);
-            mine[(2 * j + 1) * 64] = make_float4(2.0f * ub[0][j], 2.0f * ub[1][j], 2.0f * ub[2][j], 2.0f * ub[3][j]);
-        }
-    }
-}
-
-template <int HALF, bool RELU>
-__device__ __forceinline__ void wino43_finish(const float (&ua)[4][4], const float (&ub)[4][4], const float (&uc)[4][4], const float4* theirs,
-                                              const float4 b4, float* ou, bool live, bool second_row)
-{
-    const float ba[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float4 g0 = theirs[(2 * j) * 64], g1 = theirs[(2 * j + 1) * 64];
-        const float g0a[4] = {g0.x, g0.y, g0.z, g0.w}, g1a[4] = {g1.x, g1.y, g1.z, g1.w};
-        float y0[4], y1[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float p0, p1, q0, q1;                           // (P_0, P_1) of the half's two output rows
-            if (HALF == 0) { p0 = ua[r][j] + ub[r][j]; p1 = g0a[r]; q0 = uc[r][j]; q1 = g1a[r]; }
-            else           { p0 = g0a[r]; p1 = 4.0f * ua[r][j]; q0 = g1a[r]; q1 = fmaf(8.0f, ub[r][j], uc[r][j]); }
-            y0[r] = (p0 + p1) + ba[r];
-            y1[r] = (q0 + q1) + ba[r];
-            if (RELU) { y0[r] = y0[r] > 0.f ? y0[r] : 0.f; y1[r] = y1[r] > 0.f ? y1[r] : 0.f; }
-        }
-        if (live) {
-            __builtin_nontemporal_store((f32x4){y0[0], y0[1], y0[2], y0[3]}, reinterpret_cast<f32x4*>(ou + j * 16));
-            if (second_row) __builtin_nontemporal_store((f32x4){y1[0], y1[1], y1[2], y1[3]}, reinterpret_cast<f32x4*>(ou + (BX_AZI + j) * 16));
-        }
-    }
-}
 
 // ---- output transform.  nu pass and the half's partial xi sums lane-local (wino43_send), one exchange round per MFMA row tile.
 template <int NT, bool RELU>
@@ -151,8 +74,8 @@ __device__ __forceinline__ void wino43_output(const f32x4 (&acc)[NPH][RT4], floa
             const int i0 = 2 * half;                        // this half's output rows of a tile: i0, i0 + 1
             float* ou = out + ((size_t)(u * NT + ctile) * BX_EA + (4 * tr + i0) * BX_AZI + 4 * tc) * 16 + 4 * kk;
             const bool second_row = 4 * tr + i0 + 1 < BX_ELE;
-            if (half == 0) wino43_finish<0, RELU>(ua, ub, uc, theirs, b4, ou, live, second_row);
-            else wino43_finish<1, RELU>(ua, ub, uc, theirs, b4, ou, live, second_row);
+            if (half == 0) wino43_finish<0, RELU>(ua, ub, uc, theirs, b4, ou, live, second_row, BX_AZI * 16, 15u);
+            else wino43_finish<1, RELU>(ua, ub, uc, theirs, b4, ou, live, second_row, BX_AZI * 16, 15u);
         }
         __syncthreads();                                    // the exchange is free again (next row tile / next group's V planes)
     }
@@ -425,16 +348,19 @@ void g6(const double g[3], double o[6])       // the expressions of oracle/bx_or
 
 // U = G g G^T (F(4x4, 3x3)) of every (chunk, channel, output channel) in binary64, rounded once, packed as MFMA fragments
 // [chunk * 36 + plane][column tile][lane = kk*16 + li][4], element i = U[plane][chunk][kk + 4 i][channel of slot li]
-int bxk_wino43_weights(const float* w /* [nchunk][9][16][cout] */, int nchunk, int cout, float** d_out)
+int bxk_wino43_weights(const float* w /* [nchunk][9 * fold][16][cout] */, int nchunk, int fold, int cout, float** d_out)
 {
-    const int nt = cout / 16;
-    std::vector<float> frag((size_t)nchunk * NPL * nt * 64 * 4, 0.0f);
+    // fold = 3: CostNet layer 1, whose three k rows become input channels (tap = (a * 3 + b) * 3 + d; effective chunk e = chunk * 3 + b)
+    const int nt = cout / 16, ntaps = 9 * fold;
+    std::vector<float> frag((size_t)nchunk * fold * NPL * nt * 64 * 4, 0.0f);
     for (int cc = 0; cc < nchunk; ++cc)
+      for (int b = 0; b < fold; ++b)
         for (int ch = 0; ch < 16; ++ch)
             for (int o = 0; o < cout; ++o) {
                 double g[3][3], Gg[6][3];
                 for (int kh = 0; kh < 3; ++kh)
-                    for (int kw = 0; kw < 3; ++kw) g[kh][kw] = (double)w[(((size_t)cc * 9 + kh * 3 + kw) * 16 + ch) * cout + o];
+                    for (int kw = 0; kw < 3; ++kw)
+                        g[kh][kw] = (double)w[(((size_t)cc * ntaps + (fold == 3 ? (kh * 3 + b) * 3 + kw : kh * 3 + kw)) * 16 + ch) * cout + o];
                 for (int kw = 0; kw < 3; ++kw) {
                     const double col[3] = {g[0][kw], g[1][kw], g[2][kw]};
                     double r6[6];
@@ -448,7 +374,7 @@ int bxk_wino43_weights(const float* w /* [nchunk][9][16][cout] */, int nchunk, i
                         // column of the fragment = the channel's OUTPUT SLOT: the fragment is the A operand of the MFMA, so accumulator rows
                         // (4 kk + r) are contiguous slots of the output map
                         const int pl = xi * 6 + nu, kk = ch & 3, i = ch >> 2, t = o / 16, li = bx_chunk_slot(o % 16);
-                        frag[((((size_t)(cc * NPL + pl) * nt + t) * 4 + kk) * 16 + li) * 4 + i] = (float)u6[nu];
+                        frag[((((size_t)((cc * fold + b) * NPL + pl) * nt + t) * 4 + kk) * 16 + li) * 4 + i] = (float)u6[nu];
                     }
                 }
             }

@@ -77,15 +77,17 @@ typedef struct bx_params {
      * names) and is bit-exact against it; the value in force is echoed in bx_result.arith_forms.  0 = the default of each. */
     int32_t desc_conv_form;               /* Cylindrical_Net: BX_DESC_CONV_WINOGRAD43 (F(4x4,3x3), all 8 layers) | _WINOGRAD22 (F(2x2,3x3),
                                            * the 6 layers with >= 64 output channels) | _DIRECT (fp32 fmaf chain chunk > tap > channel) */
-    int32_t pose_conv_form;               /* CostNet layers 1..5: BX_POSE_CONV_WINOGRAD (valid F(2x2,3x3)) | BX_POSE_CONV_DIRECT */
+    int32_t pose_conv_form;               /* CostNet layers 1..5: BX_POSE_CONV_WINOGRAD43 (valid F(4x4,3x3)) | _WINOGRAD22 (valid F(2x2,3x3)) |
+                                           * _DIRECT */
     int32_t cost_l0_form;                 /* CostNet layer 0: BX_COST_L0_COLLAPSED (binary64 P - Q form) | BX_COST_L0_DIRECT (fp32
                                            * convolution of the implicit cost volume) */
 } bx_params;
 #define BX_DESC_CONV_WINOGRAD43 0
 #define BX_DESC_CONV_WINOGRAD22 1
 #define BX_DESC_CONV_DIRECT 2
-#define BX_POSE_CONV_WINOGRAD 0
-#define BX_POSE_CONV_DIRECT 1
+#define BX_POSE_CONV_WINOGRAD43 0
+#define BX_POSE_CONV_WINOGRAD22 1
+#define BX_POSE_CONV_DIRECT 2
 #define BX_COST_L0_COLLAPSED 0
 #define BX_COST_L0_DIRECT 1
 

@@ -181,17 +181,31 @@ def conv_wino_valid(x, W, bias, relu, D, fold):
     return out
 
 
+def conv_wino43_valid(x, W, bias, relu, D, fold):
+    """CostNet layer as a valid Winograd F(4x4, 3x3) convolution over a D x D map (bxo_conv_wino43_valid); arguments as conv_wino_valid."""
+    x, W, bias = _f(x), _f(W), _f(bias)
+    units, n_chunks, p_in, _ = x.shape
+    cout = W.shape[-1]
+    assert p_in == D * fold * D and W.shape == (n_chunks, 9 * fold, 16, cout), (x.shape, W.shape, D, fold)
+    out = np.zeros((units, (cout + 15) // 16, (D - 2) * (D - 2), 16), np.float32)
+    lib().bxo_conv_wino43_valid(_p(x), C.c_int(units), C.c_int(n_chunks), C.c_int(D), C.c_int(fold), _p(W), _p(bias), C.c_int(cout),
+                                C.c_int(int(relu)), _p(out))
+    return out
+
+
 def _default_form(key):
     import bufferx_amd.config as _c       # the product's knob table: the default of every arithmetic form lives in ONE place
     return _c.ARITH_DEFAULT[key]
 
 
 def pose_conv(layer, x, tap, dims, W, bias, relu, form=None):
-    """CostNet layer `layer` (1..9) in the arithmetic form `form` of bx_params.pose_conv_form ("winograd": layers 1..5 as valid
-    F(2x2, 3x3) convolutions, wino_pose_kernel | "direct": conv_kernel); dims = input dims (n, k, l) of the layer."""
+    """CostNet layer `layer` (1..9) in the arithmetic form `form` of bx_params.pose_conv_form ("winograd43": layers 1..5 as valid
+    F(4x4, 3x3) convolutions, wino43v_kernel | "winograd22": valid F(2x2, 3x3), wino_pose_kernel | "direct": conv_kernel); dims = input dims (n, k, l) of the layer."""
     form = form or _default_form("pose_conv")
-    assert form in ("winograd", "direct"), form
-    if form == "winograd" and 1 <= layer <= 5:
+    assert form in ("winograd43", "winograd22", "direct"), form
+    if form == "winograd43" and 1 <= layer <= 5:
+        return conv_wino43_valid(x, W, bias, relu, dims[0], dims[1])
+    if form == "winograd22" and 1 <= layer <= 5:
         return conv_wino_valid(x, W, bias, relu, dims[0], dims[1])
     return conv(x, tap, W, bias, relu)
 

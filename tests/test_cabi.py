@@ -56,8 +56,8 @@ def test_arith_forms_table():
     from bufferx_amd import lib, config
     hdr = open(os.path.join(ROOT, "include", "bufferx.h")).read()
     for macro, key, name in (("BX_DESC_CONV_WINOGRAD43", "desc_conv", "winograd43"), ("BX_DESC_CONV_WINOGRAD22", "desc_conv", "winograd22"),
-                             ("BX_DESC_CONV_DIRECT", "desc_conv", "direct"), ("BX_POSE_CONV_WINOGRAD", "pose_conv", "winograd"),
-                             ("BX_POSE_CONV_DIRECT", "pose_conv", "direct"), ("BX_COST_L0_COLLAPSED", "cost_l0", "collapsed"),
+                             ("BX_DESC_CONV_DIRECT", "desc_conv", "direct"), ("BX_POSE_CONV_WINOGRAD22", "pose_conv", "winograd22"),
+                             ("BX_POSE_CONV_DIRECT", "pose_conv", "direct"), ("BX_POSE_CONV_WINOGRAD43", "pose_conv", "winograd43"), ("BX_COST_L0_COLLAPSED", "cost_l0", "collapsed"),
                              ("BX_COST_L0_DIRECT", "cost_l0", "direct")):
         v = int(re.search(r"#define %s (\d+)" % macro, hdr).group(1))
         assert config.ARITH_FORMS[key][v] == name
@@ -68,9 +68,9 @@ def test_arith_forms_table():
         cfg = bufferx_amd.make_cfg("3DMatch")
         p = lib.params_from_cfg(cfg, 1000)
         assert (p.desc_conv_form, p.pose_conv_form, p.cost_l0_form) == (0, 0, 0)
-        cfg.arith.desc_conv, cfg.arith.cost_l0 = "direct", "direct"
+        cfg.arith.desc_conv, cfg.arith.pose_conv, cfg.arith.cost_l0 = "direct", "winograd22", "direct"
         p = lib.params_from_cfg(cfg, 1000)
-        assert (p.desc_conv_form, p.pose_conv_form, p.cost_l0_form) == (2, 0, 1)
+        assert (p.desc_conv_form, p.pose_conv_form, p.cost_l0_form) == (2, 1, 1)
         cfg.arith.pose_conv = "fast"
         try:
             lib.params_from_cfg(cfg, 1000)

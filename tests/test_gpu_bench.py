@@ -48,7 +48,7 @@ def test_world2_records_equal_world1(tmp_path):
         assert [e["inflight"] for e in j["inflight_sweep"]] == [1, 2] and all(e["pairs_per_s"] > 0 for e in j["inflight_sweep"])
         # the roofline fields are fractions of a peak: flops ISSUED on the matrix pipe, never above 1
         assert 0 < j["roofline"]["frac"] <= 1.0 and 0 < j["roofline_costnet"]["frac"] <= 1.0 and j["roofline"]["algorithmic_rate_x_peak"] > 0
-        assert j["config"]["arithmetic_forms"] == {"desc_conv": "winograd43", "pose_conv": "winograd", "cost_l0": "collapsed"}
+        assert j["config"]["arithmetic_forms"] == {"desc_conv": "winograd43", "pose_conv": "winograd43", "cost_l0": "collapsed"}
     assert j1["registered_ok"] == j2["registered_ok"] == j3["registered_ok"]
     assert j1["host_ms_per_pair"] > 0
     e2e = j1["e2e_pairs_per_s"]          # files -> poses leg (N = 1 only): both RNG modes produce a rate

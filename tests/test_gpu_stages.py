@@ -259,7 +259,7 @@ def test_desc_conv_every_form(oracle, bx, packed, form):
         c.close()
 
 
-@pytest.mark.parametrize("form", ["winograd", "direct"])
+@pytest.mark.parametrize("form", ["winograd43", "winograd22", "direct"])
 def test_pose_conv_every_form(oracle, bx, packed, form):
     """bx_params.pose_conv_form: CostNet layers 1..5 in both forms against their restatements."""
     from bufferx_amd import lib
@@ -272,7 +272,7 @@ def test_pose_conv_every_form(oracle, bx, packed, form):
             dims, k, _ = bx.weights.pose_geometry()[layer]
             tap, od = bx.weights.valid_tap_table(dims, k)
             rng = np.random.default_rng(200 + layer)
-            x = rng.standard_normal((7, L["W"].shape[0], int(np.prod(dims)), 16)).astype(np.float32)
+            x = rng.standard_normal((19, L["W"].shape[0], int(np.prod(dims)), 16)).astype(np.float32)     # 19 units: ragged last group for G = 2, 3, 8
             ref = oracle.pose_conv(layer, x, tap, dims, L["W"], L["b"], L["relu"], form=form)
             out = c.conv_layer(1, layer, lib.logical_to_chunked(x), ref.shape)
             assert np.array_equal(lib.chunked_to_logical(_np(out)), ref), (form, layer)

@@ -28,7 +28,7 @@ NPAIRS = 32
 K, P, S = 5000, 1024, 3
 
 
-def _cfg(bx, workload, form):
+def _cfg(bx, workload, form, key="desc_conv"):
     import bench
     cfg = bx.make_cfg(bench.WORKLOADS[workload][0])
     cfg.patch.num_fps, cfg.patch.num_points_per_patch, cfg.patch.num_scales = K, P, S
@@ -36,7 +36,7 @@ def _cfg(bx, workload, form):
     if workload == "tiers":
         cfg.match.enable_early_exit = True
         cfg.match.early_exit_min_inliers = 50
-    cfg.arith.desc_conv = form
+    cfg.arith[key] = form
     return cfg
 
 
@@ -46,19 +46,28 @@ def _key(ss, tt):
 
 @pytest.mark.parametrize("workload", ["3dmatch", "kitti", "tiers", "3dlomatch"])
 def test_forms_agree(bx, packed, workload):
+    _sweep(bx, packed, workload, "desc_conv", ["direct", "winograd22", "winograd43"])
+
+
+@pytest.mark.parametrize("workload", ["3dmatch", "kitti", "tiers", "3dlomatch"])
+def test_pose_forms_agree(bx, packed, workload):
+    """The same sweep over the forms of CostNet's layers 1..5 (direct | valid F(2x2, 3x3) | valid F(4x4, 3x3)): they feed the soft-argmax whose
+    output becomes the in-plane angle of every pose hypothesis, i.e. they can move a hypothesis across the consensus threshold."""
+    _sweep(bx, packed, workload, "pose_conv", ["direct", "winograd22", "winograd43"])
+
+
+def _sweep(bx, packed, workload, key, forms):
     import torch
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
     import bench
     from bufferx_amd import lib
-    default_form = bx.config.ARITH_FORMS["desc_conv"][0]
-    forms = ["direct", "winograd22", "winograd43"]
     pairs = [bench.make_pair(bx, workload, 300 + i) for i in range(NPAIRS)]
     nmax = max(max(len(p["src"]), len(p["tgt"])) for p in pairs)
     cap_scale = 0 if workload == "tiers" else S - 1          # early exit: the pair ends after scale 0 when the exit is taken
     runs = {}
     for form in forms:
-        ctx = lib.Context(_cfg(bx, workload, form), max_points=nmax, device=0, packed_weights=packed)
+        ctx = lib.Context(_cfg(bx, workload, form, key), max_points=nmax, device=0, packed_weights=packed)
         cap = ctx.set_capture(cap_scale, 0, nmax)
         out = []
         for i, p in enumerate(pairs):
@@ -67,7 +76,7 @@ def test_forms_agree(bx, packed, workload):
             pt = np.stack([rng.permutation(len(p["tgt"])).astype(np.int32) for _ in range(S)])
             r = ctx.register_pair(p["src"], p["tgt"], p["aligned_z"], ps, pt, 300 + i)
             torch.cuda.synchronize()
-            assert r.status == 0 and lib.forms_of_result(r)["desc_conv"] == form
+            assert r.status == 0 and lib.forms_of_result(r)[key] == form
             cnt = cap["counts"].cpu().numpy()
             M, C = int(cnt[1]), int(cnt[2])
             ss, tt = cap["ss_cat"][:M].cpu().numpy().copy(), cap["tt_cat"][:M].cpu().numpy().copy()
@@ -79,7 +88,7 @@ def test_forms_agree(bx, packed, workload):
         ctx.close()
     reports = []
     for form in forms[1:]:
-        rep = dict(workload=workload, pairs=NPAIRS, form=form, vs="direct", pairs_with_flipped_matches=0, flipped_matches=0,
+        rep = dict(workload=workload, pairs=NPAIRS, stage=key, form=form, vs="direct", pairs_with_flipped_matches=0, flipped_matches=0,
                    matches_total=int(sum(o["M"] for o in runs["direct"])), pairs_with_other_consensus=0, consensus_members_flipped=0,
                    pairs_with_other_ransac_inliers=0, max_pose_deg=0.0, max_pose_m=0.0, scales_used=[0] * (S + 1),
                    mean_C=float(np.mean([len(o["consensus"]) for o in runs["direct"]])), min_C=int(min(len(o["consensus"]) for o in runs["direct"])))
