@@ -145,13 +145,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--inflight", type=int, default=8, help="pairs in flight per GPU (contexts / HIP streams)")
+    ap.add_argument("--inflight", type=int, default=16, help="pairs in flight per GPU (contexts / HIP streams); measured 8 / 12 / 16 / 24 / 32: 50.8 / 51.9 / 52.6 / 49.7 / 50.6 pairs/s")
     ap.add_argument("--lane", type=int, default=0, help="bx_lane mode ordering the pairs in flight: 0 none, 1 whole main phase, 2 conv stacks")
     ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic pairs (cycled; the same list on every rank); N of every cloud is drawn from U[20k, 60k]")
     ap.add_argument("--desc-conv", default=None, choices=["winograd43", "winograd22", "direct"], help="bx_params.desc_conv_form (default: the library default)")
     ap.add_argument("--pose-conv", default=None, choices=["winograd43", "winograd22", "direct"], help="bx_params.pose_conv_form")
     ap.add_argument("--cost-l0", default=None, choices=["collapsed", "direct"], help="bx_params.cost_l0_form")
-    ap.add_argument("--inflight-sweep", default="1,2,4,8", help="pairs in flight of the throughput-vs-latency sweep after the timed region ('' = skip)")
+    ap.add_argument("--inflight-sweep", default="1,2,4,8,16", help="pairs in flight of the throughput-vs-latency sweep after the timed region ('' = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e-pairs", type=int, default=24, help="pairs of the file-driven end-to-end measurement per RNG mode (0 = skip; N = 1 only)")
     ap.add_argument("--num-fps", type=int, default=5000)
