@@ -40,7 +40,7 @@ def stack(pred):
 
 
 d_busy, d_clk = stack(lambda k: k.startswith("conv_kernel<") and ", 140, 198, 140," in k or k.startswith("conv32_kernel<") or k.startswith("wino_kernel<") or k.startswith("wino_pair_kernel<") or k.startswith("wino43_kernel<"))
-c_busy, c_clk = stack(lambda k: k.startswith("cost_l1_kernel") or k.startswith("wino_pose_kernel<") or (k.startswith("conv_kernel<") and ", 140, 198, 140," not in k))   # MFMA kernels of CostNet (layers 1..9; the collapsed layer 0, cost_l0_kernel, is binary64 VALU work and has no MFMA cycles)
+c_busy, c_clk = stack(lambda k: k.startswith("cost_l1_kernel") or k.startswith("wino_pose_kernel<") or k.startswith("wino43v_kernel<") or (k.startswith("conv_kernel<") and ", 140, 198, 140," not in k))   # MFMA kernels of CostNet (layers 1..9; the collapsed layer 0, cost_l0_kernel, is binary64 VALU work and has no MFMA cycles)
 out["desc_conv_stack"] = d_busy
 out["desc_conv_stack_clock_GHz"] = d_clk
 out["costnet"] = c_busy
