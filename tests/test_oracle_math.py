@@ -186,6 +186,33 @@ def test_winograd43_layers_close_to_direct_form(oracle, bx, packed):
         assert np.abs(oracle.conv(x, tap, L["W"], L["b"], True) - oracle.conv_wino43(x, L["W"], L["b"], True)).max() < 2e-5
 
 
+def test_valid_winograd43_layers_close_to_direct_form(oracle, bx, packed):
+    """bxo_conv_wino43_valid (valid F(4x4, 3x3), the contract of k_wino43v.hip and the default form of CostNet layers 1..5) against bxo_conv
+    and against the F(2x2) form: D = 18 (folded k rows), 16 and 12 (last tiles reach beyond the map: zero rows / dropped outputs), 14, 10;
+    chained like the network; and a one-hot map at the corners / the partial last tile of every layer."""
+    rng = np.random.default_rng(2)
+    geo = bx.weights.pose_geometry()
+    dims0 = geo[1][0]
+    x = np.abs(rng.standard_normal((5, 2, int(np.prod(dims0)), 16))).astype(np.float32)
+    for layer in range(1, 6):
+        L = packed["pose"][layer]
+        dims, k, _ = geo[layer]
+        tap, _ = bx.weights.valid_tap_table(dims, k)
+        a = oracle.conv(x, tap, L["W"], L["b"], L["relu"])
+        b = oracle.conv_wino43_valid(x, L["W"], L["b"], L["relu"], dims[0], dims[1])
+        c = oracle.conv_wino_valid(x, L["W"], L["b"], L["relu"], dims[0], dims[1])
+        scale = max(1.0, float(np.abs(a).max()) / 5.0)
+        assert a.shape == b.shape == c.shape
+        assert np.abs(a - b).max() < 1e-4 * scale and np.abs(a - c).max() < 2e-5 * scale, (layer, np.abs(a - b).max(), np.abs(a - c).max())
+        D, fold = dims[0], dims[1]
+        for (n, l) in ((0, 0), (0, D - 1), (D - 1, 0), (D - 1, D - 1), (D - 3, D - 3), (4, 3)):
+            h = np.zeros((1, L["W"].shape[0], D * fold * D, 16), np.float32)
+            for kk in range(fold):
+                h[0, :, (n * fold + kk) * D + l, :] = 1.0
+            assert np.abs(oracle.conv(h, tap, L["W"], L["b"], True) - oracle.conv_wino43_valid(h, L["W"], L["b"], True, D, fold)).max() < 2e-5, (layer, n, l)
+        x = a
+
+
 def test_collapsed_cost_layer_close_to_direct_form(oracle, bx, packed):
     """bxo_cost_l0 (binary64 P - Q form, the contract of k_cost.hip) against the fp32 convolution of the materialised cost volume
     (CostVolume.forward + the first Conv3d, models/BUFFERX.py:59-65, models/patchnet.py:196), incl. nearly equal maps (P - Q cancels)."""
