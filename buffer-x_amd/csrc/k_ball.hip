@@ -28,6 +28,10 @@
 #include <cstring>
 
 
+#ifndef BX_BALL_NOPRE_LOGC
+#define BX_BALL_NOPRE_LOGC 5       // clouds of more than 65 536 points
+#endif
+
 namespace {
 
 __global__ void permute_kernel(const float* __restrict__ pts, const int32_t* __restrict__ perm, int n, float* __restrict__ out,
@@ -423,8 +427,12 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
 #define BX_TR(k) do { if (tr) td[k] = __builtin_readcyclecounter() - t0; } while (0)
     unsigned long long* bm64 = reinterpret_cast<unsigned long long*>(smem);
     unsigned int* bm32 = reinterpret_cast<unsigned int*>(smem);
-    int* pre = reinterpret_cast<int*>(smem + (size_t)NW64 * 8);            // [NW64] set bits in front of every 64-bit word
-    int* list = reinterpret_cast<int*>(smem + (size_t)NW64 * 12);          // [P]
+    // large clouds (LOGC >= BX_BALL_NOPRE_LOGC: bitmaps of 16 KB and more): no per-word prefix array -- the owners of the bitmap words expand
+    // their bits themselves (the self-ranking of the hits needs the array) -- so that the workgroup's LDS shrinks by a third and more
+    // keypoints are resident per CU
+    constexpr bool NOPRE = LOGC >= BX_BALL_NOPRE_LOGC;
+    int* pre = reinterpret_cast<int*>(smem + (size_t)NW64 * 8);            // [NW64] set bits in front of every 64-bit word (!NOPRE)
+    int* list = reinterpret_cast<int*>(smem + (size_t)NW64 * (NOPRE ? 8 : 12));          // [P]
 
     {
         ulonglong2* z = reinterpret_cast<ulonglong2*>(bm64 + (size_t)tid * CW);
@@ -432,7 +440,7 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
         for (int s = 0; s < CW / 2; ++s) z[s] = make_ulonglong2(0ULL, 0ULL);
     }
 
-    int2* ptl = reinterpret_cast<int2*>(smem + (size_t)NW64 * 12 + (((size_t)P * 4 + 7) & ~(size_t)7));   // [NPMAX] piece table of this keypoint
+    int2* ptl = reinterpret_cast<int2*>(smem + (size_t)NW64 * (NOPRE ? 8 : 12) + (((size_t)P * 4 + 7) & ~(size_t)7));   // [NPMAX] piece table of this keypoint
     const int NP = __builtin_amdgcn_readfirstlane(pnum[q]);                          // -1: degenerate geometry
     for (int i = tid; i < NP; i += QT) ptl[i] = ptab[(size_t)q * NPMAX + i];
     const float r = (float)(*radius);
@@ -445,7 +453,7 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
     constexpr int MAXIT = 16;                               // iterations whose hits are kept in registers and rank themselves
     const int GP = 64 >> logpw;                             // pieces per wave and iteration
     const int nit = NP > 0 ? (NP + QW * GP - 1) / (QW * GP) : 0;   // uniform
-    const bool one_block = NP >= 0 && nit <= MAXIT;
+    const bool one_block = !NOPRE && NP >= 0 && nit <= MAXIT;
     int hidx[MAXIT];                                        // one_block: index of the hit of iteration it, -1 otherwise
 #pragma unroll
     for (int u = 0; u < MAXIT; ++u) hidx[u] = -1;
@@ -604,7 +612,7 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
 template <int LOGC, int QW>
 int launch_query_w(bx_ctx* c, hipStream_t s, int set, int k0, int K, const float* kpts, const double* radius, int P, int32_t* idx_out, float* patches_out)
 {
-    const size_t lds = ((size_t)64 << LOGC) * 12 + (((size_t)P * 4 + 7) & ~(size_t)7) + (size_t)NPMAX * 8;   // bitmap | per-word prefix | ordered index list | pieces
+    const size_t lds = ((size_t)64 << LOGC) * (LOGC >= BX_BALL_NOPRE_LOGC ? 8 : 12) + (((size_t)P * 4 + 7) & ~(size_t)7) + (size_t)NPMAX * 8;   // bitmap | per-word prefix | ordered index list | pieces
     if (lds > 160 * 1024) { bx_set_error("bxk_ball_group: P=%d needs %zu B of LDS per keypoint (> 160 KiB)", P, lds); return BX_ERR_ARG; }
     if (lds > 64 * 1024 && !(c->ball_attr_set & (1LL << (LOGC * 3 + QW / 2)))) {
         BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_kernel<LOGC, QW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
