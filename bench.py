@@ -351,7 +351,7 @@ def main():
         # launches that did work: with the early exit taken the kernels of the later scales return at once (device-side skip
         # flag) but are still bracketed by events -- per-launch averages are taken over the scales that ran
         ran = mean_scales / S
-        CONV_SRC = ("k_conv.hip", "k_wino.hip", "k_wino43.hip", "bx_common.h")
+        CONV_SRC = ("k_conv.hip", "k_wino.hip", "k_wino43.hip", "k_wino43v.hip", "wino43_common.h", "bx_common.h")
         pmc = profile_json("pmc_traffic", CONV_SRC)
         pmc_ball = profile_json("pmc_traffic", ("k_ball.hip", "bx_common.h"))
         busy = profile_json("mfma_busy", CONV_SRC)

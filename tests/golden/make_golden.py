@@ -53,6 +53,12 @@ CASES = {
     # BASELINE configs[2] geometry at its real size: two ~120k-point LiDAR sweeps, the reference's KITTI configuration (aligned z,
     # confidence 1.0 = all 50 000 RANSAC iterations, no refinement -> binary64 pose), 3 scales, 5000 keypoints, 1024 points per patch
     "kitti_cfg2": ("KITTI", "kitti_full", 0, 100, dict(num_fps=5000, num_points_per_patch=1024, sub_stride=256, row_stride=4)),
+    # round 4: three more pairs at the REAL size (K = 5000 / P = 1024 / S = 3) -- two of bench.py's own 3DMatch-like pairs (seeds 103, 112; with
+    # the fixture's permutations both register) and a second pair of LiDAR sweeps -- so that "counts / mutual sets / consensus sets identical
+    # to the reference's at real size" rests on six pairs, not three (7.5 CPU-minutes each on 8 cores)
+    "headline_cfg1_b": ("3DMatch", "indoor_shared", 36885, 103, dict(num_fps=5000, num_points_per_patch=1024, sub_stride=256, row_stride=4)),
+    "headline_cfg1_c": ("3DMatch", "indoor_shared", 28334, 112, dict(num_fps=5000, num_points_per_patch=1024, sub_stride=256, row_stride=4)),
+    "kitti_cfg2_b": ("KITTI", "kitti_full", 0, 101, dict(num_fps=5000, num_points_per_patch=1024, sub_stride=256, row_stride=4)),
     # round 4: more pairs at a size where matching is no longer sparse (1 000 - 1 500 keypoints on 4 000 - 6 000-point fragments: a quarter of
     # the keypoints coincide, so the pairs REGISTER with the seeded random weights; 3 scales, the reference's own defaults otherwise), other
     # seeds / densities, so that "F(4x4, 3x3) keeps the reference's mutual and consensus sets" rests on more than three real-size pairs;

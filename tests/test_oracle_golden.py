@@ -117,7 +117,7 @@ def test_oracle_pipeline_matches_reference(bx, packed, golden_dir, name):
 
 # ------------------------------------------------------------------ the real-size fixtures (K = 5000 / P = 1024 / S = 3)
 @pytest.mark.skipif(not os.environ.get("BX_RUN_BIG_ORACLE"), reason="3-4 CPU-minutes per case: set BX_RUN_BIG_ORACLE=1 (results quoted in DESIGN.md section 4)")
-@pytest.mark.parametrize("name", ["headline_cfg1", "kitti_cfg2", "tiers_early"])
+@pytest.mark.parametrize("name", ["headline_cfg1", "kitti_cfg2", "tiers_early"])      # (the round-4 real-size fixtures are checked on the GPU: tests/test_gpu_headline.py)
 def test_oracle_matches_reference_at_real_size(bx, packed, golden_dir, name):
     """The CPU oracle pipeline against the fixture minted by the reference's own forward at BASELINE configs[1] / [2] / [4] size:
     identical counts, mutual sets, consensus set; pose within 1e-4 deg / 1e-4 m; >= 99.8 % of the sampled descriptor rows within 2e-5."""
