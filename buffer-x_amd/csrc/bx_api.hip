@@ -907,9 +907,11 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
     // every scale's radius up front (the bisections share the histogram: one launch), then the grids of all 2 x S (cloud, scale)
     // sets in one batch of six launches; the per-scale permutation is applied on the fly
     { ProfScope ps(c, s, 1); if ((rc = bxk_radius_bisect_all(c, s, (int64_t)ns[big], NK, p.search_radius_thresholds, S, st->des_r)) != BX_OK) return rc; }
-    { ProfScope ps(c, s, 13); if ((rc = bxk_ball_grids(c, s, clouds, ns, perms, 2, st->des_r, S, p.search_radius_thresholds)) != BX_OK) return rc; }
-
+    // (with the early exit on, only scale 0's two grids: the later scales' are built behind the exit test and skipped with the pair)
     const bool early = p.enable_early_exit != 0;
+    c->skip = nullptr;
+    { ProfScope ps(c, s, 13); if ((rc = bxk_ball_grids(c, s, clouds, ns, perms, 2, st->des_r, S, p.search_radius_thresholds, 0, early ? 1 : S)) != BX_OK) return rc; }
+
     // descriptors of keypoints [k0, k0 + kn) of one (scale, cloud): neighbour gather -> patch features -> Cylindrical_Net
     // Latency form: the target cloud's chain runs on the context's second stream with its own scratch, so that the tail of one
     // chain's launch is filled by the other's (the same overlap several pairs in flight give the throughput form).
@@ -961,7 +963,7 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
     for (int t = 0; t < T; ++t) {
         const int k0 = tb[t], kn = (t == T - 1 ? K : tb[t + 1]) - k0;
         if (tiled && t > 0) BX_HIP(hipStreamWaitEvent(s, c->ev_tile[t], 0));
-        { ProfScope ps(c, s, 13); if ((rc = bxk_ball_rows(c, s, c->kpts, 2, S, k0, kn)) != BX_OK) return rc; }
+        { ProfScope ps(c, s, 13); if ((rc = bxk_ball_rows(c, s, c->kpts, 2, S, k0, kn, 0, early ? 1 : S)) != BX_OK) return rc; }
         if (!multi) break;
         if ((rc = tgt_go()) != BX_OK) return rc;
         for (int i = 0; i < (early ? 1 : S); ++i)
@@ -982,6 +984,12 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
         }
         c->skip = (early && i > 0) ? &st->done : nullptr;
         const bool capi = c->cap_on && c->cap.scale == i;
+        if (early && i == 1) {
+            // the grids and candidate tables of scales 1 .. S - 1, behind the exit test of scale 0 (nothing is built for a pair that left)
+            ProfScope ps(c, s, 13);
+            if ((rc = bxk_ball_grids(c, s, clouds, ns, perms, 2, st->des_r, S, p.search_radius_thresholds, 1, S - 1)) != BX_OK) return rc;
+            if ((rc = bxk_ball_rows(c, s, c->kpts, 2, S, 0, K, 1, S - 1)) != BX_OK) return rc;
+        }
         if (!multi || (early && i > 0)) {
             if ((rc = tgt_go()) != BX_OK) return rc;
             for (int cl = 0; cl < 2; ++cl)

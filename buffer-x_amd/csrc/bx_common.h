@@ -213,8 +213,8 @@ int bxk_ball_group(bx_ctx* c, hipStream_t s, const float* pts_perm, int n, const
 int bxk_ball_prepare(bx_ctx* c, hipStream_t s, const float* const* clouds, const int* ns, const int32_t* const* perms,
                      const float* const* kpts, int nclouds, int K, const double* radius, int S, const double* pw_hint);
 int bxk_ball_grids(bx_ctx* c, hipStream_t s, const float* const* clouds, const int* ns, const int32_t* const* perms, int nclouds,
-                   const double* radius, int S, const double* pw_hint);
-int bxk_ball_rows(bx_ctx* c, hipStream_t s, const float* const* kpts, int nclouds, int S, int k0, int K);
+                   const double* radius, int S, const double* pw_hint, int i0 = 0, int ni = -1);      // scales [i0, i0 + ni) (ni < 0: to S); honours c->skip
+int bxk_ball_rows(bx_ctx* c, hipStream_t s, const float* const* kpts, int nclouds, int S, int k0, int K, int i0 = 0, int ni = -1);
 int bxk_ball_query(bx_ctx* c, hipStream_t s, int set, int n, const float* kpts, int k0, int K, const double* radius, int P,
                    int32_t* idx_out, float* patches_out);
 int bxk_radius_bisect_all(bx_ctx* c, hipStream_t s, int64_t n_orig, int nk, const double* thresholds_host, int nthr, double* des_r_out);

@@ -66,6 +66,8 @@ struct BallBatch {
     const float* kpts[2];
     int n[2];
     int S, nsets, K;
+    int i0, ni;                 // the scales [i0, i0 + ni) of every cloud are in this batch: launch row y -> cloud y / ni, scale i0 + y % ni
+    const int32_t* skip;        // device flag, nullptr or *skip != 0: the batch does nothing (the pair left by the early exit)
     const double* radius;       // device: radius of scale i at radius[i]
     // per-set arrays: element j at base + j * stride
     float* bbox_part;           // [2][64][6]
@@ -79,10 +81,20 @@ struct BallBatch {
     int logpw[BX_MAX_SCALES];   // piece width of scale i: 64 / 16 / 8 candidates by the expected length of a cell row
 };
 
+// launch row -> (set, cloud, scale) of a batch; false when the batch is switched off
+__device__ __forceinline__ bool ball_set(const BallBatch& B, int y, int& j, int& cl, int& sc)
+{
+    cl = y / B.ni;
+    sc = B.i0 + (y - cl * B.ni);
+    j = cl * B.S + sc;
+    return !(B.skip != nullptr && *B.skip != 0);
+}
+
 // per-block partial bounds of a cloud (64 blocks x 2 clouds, no atomics, no initialisation launch)
 __global__ __launch_bounds__(1024) void bbox_kernel(BallBatch B)
 {
     __shared__ float red[16][6];
+    if (B.skip != nullptr && *B.skip != 0) return;
     const int cl = blockIdx.y;
     const float* __restrict__ pts = B.pts[cl];
     const int n = B.n[cl];
@@ -121,7 +133,8 @@ __global__ __launch_bounds__(1024) void bbox_kernel(BallBatch B)
 // one wave per set: grid geometry from the cloud's bounds and the device-side radius of the set's scale
 __global__ __launch_bounds__(64) void grid_setup_kernel(BallBatch B, int div)
 {
-    const int j = blockIdx.x, cl = j / B.S, sc = j - cl * B.S;
+    int j, cl, sc;
+    if (!ball_set(B, blockIdx.x, j, cl, sc)) return;
     const int lane = threadIdx.x;
     float v[6];
 #pragma unroll
@@ -188,7 +201,8 @@ constexpr int COUNT_PPT = 4;   // points per thread (register-resident between t
 __global__ __launch_bounds__(1024) void cell_count_kernel(BallBatch B)
 {
     __shared__ int hist[COUNT_LDS_CELLS];
-    const int j = blockIdx.y, cl = j / B.S, sc = j - cl * B.S;
+    int j, cl, sc;
+    if (!ball_set(B, blockIdx.y, j, cl, sc)) return;
     const int n = B.n[cl];
     const int base = blockIdx.x * (1024 * COUNT_PPT);
     if (base >= n) return;
@@ -239,7 +253,8 @@ constexpr int SCAN_TILE = 2048;   // cells per 256-thread workgroup
 __global__ __launch_bounds__(256) void scan_sums_kernel(BallBatch B)
 {
     __shared__ int ws[4];
-    const int j = blockIdx.y;
+    int j, cl_, sc_;
+    if (!ball_set(B, blockIdx.y, j, cl_, sc_)) return;
     const int32_t* __restrict__ cnt = B.cnt + (size_t)j * B.st_cnt;
     const int base = blockIdx.x * SCAN_TILE;
     int s = 0;
@@ -259,7 +274,8 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(BallBatch B)
 {
     __shared__ int ws[4];
     __shared__ int boff;
-    const int j = blockIdx.y;
+    int j, cl_, sc_;
+    if (!ball_set(B, blockIdx.y, j, cl_, sc_)) return;
     int32_t* __restrict__ cnt = B.cnt + (size_t)j * B.st_cnt;
     int32_t* __restrict__ start = B.start + (size_t)j * B.st_cnt;
     const int32_t* __restrict__ bsum = B.bsum + (size_t)j * B.st_bsum;
@@ -290,7 +306,8 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(BallBatch B)
 
 __global__ __launch_bounds__(256) void cell_scatter_kernel(BallBatch B)
 {
-    const int j = blockIdx.y, cl = j / B.S;
+    int j, cl, sc_;
+    if (!ball_set(B, blockIdx.y, j, cl, sc_)) return;
     const int n = B.n[cl];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -315,7 +332,8 @@ constexpr int NPMAX = 256;       // piece-table capacity per keypoint
 // 64 at the 5 % scale (rows of ~50 candidates), 16 at 2 %, 8 at 0.5 % (rows of ~4).
 __global__ __launch_bounds__(256) void ball_rows_kernel(BallBatch B, int trim)
 {
-    const int j_ = blockIdx.y, cl_ = j_ / B.S, sc_ = j_ - cl_ * B.S;
+    int j_, cl_, sc_;
+    if (!ball_set(B, blockIdx.y, j_, cl_, sc_)) return;
     const int32_t* __restrict__ start = B.start + (size_t)j_ * B.st_cnt;
     const BallGrid* __restrict__ g = B.grid + j_;
     const float* __restrict__ kpts = B.kpts[cl_];
@@ -692,8 +710,10 @@ void batch_from_ctx(const bx_ctx* c, BallBatch& B)
 // Cell grids of `nclouds` clouds x S scales in six launches (see BallBatch).  clouds / perms: per cloud; perm[cl] is [S][n] or
 // nullptr (identity).  radius: device array of S doubles.  Independent of the keypoints.
 int bxk_ball_grids(bx_ctx* c, hipStream_t s, const float* const* clouds, const int* ns, const int32_t* const* perms, int nclouds,
-                   const double* radius, int S, const double* pw_hint)
+                   const double* radius, int S, const double* pw_hint, int i0, int ni)
 {
+    if (ni < 0) ni = S - i0;
+    if (i0 < 0 || ni < 1 || i0 + ni > S) { bx_set_error("bxk_ball_grids: scales [%d, %d) of %d", i0, i0 + ni, S); return BX_ERR_ARG; }
     if (nclouds < 1 || nclouds > 2 || S < 1 || nclouds * S > c->ball_nsets) {
         bx_set_error("bxk_ball_prepare: %d clouds x %d scales exceed the context's %d grid sets", nclouds, S, c->ball_nsets);
         return BX_ERR_ARG;
@@ -707,8 +727,8 @@ int bxk_ball_grids(bx_ctx* c, hipStream_t s, const float* const* clouds, const i
         B.pts[cl] = clouds[cl]; B.perm[cl] = perms ? perms[cl] : nullptr; B.n[cl] = ns[cl];
         nmax = ns[cl] > nmax ? ns[cl] : nmax;
     }
-    B.S = S; B.nsets = nclouds * S; B.radius = radius;
-    for (int i = 0; i < S; ++i) {
+    B.S = S; B.nsets = nclouds * ni; B.radius = radius; B.i0 = i0; B.ni = ni; B.skip = c->skip;
+    for (int i = i0; i < i0 + ni; ++i) {
         // piece width by the share of the cloud a ball of this scale is expected to hold (its cell rows are ~1/40 of that): the
         // percentage thresholds of the pair path (cfg.patch.search_radius_thresholds), 64 when unknown (stage entry point)
         const double thr = pw_hint ? pw_hint[i] : 100.0;
@@ -718,7 +738,7 @@ int bxk_ball_grids(bx_ctx* c, hipStream_t s, const float* const* clouds, const i
     const int nb = (nmax + 255) / 256;
     const int nb4k = (nmax + 1024 * COUNT_PPT - 1) / (1024 * COUNT_PPT);
     const int ntile = BX_BALL_NCELL / SCAN_TILE + 1;
-    hipLaunchKernelGGL(bbox_kernel, dim3(64, nclouds), dim3(1024), 0, s, B);
+    if (i0 == 0) hipLaunchKernelGGL(bbox_kernel, dim3(64, nclouds), dim3(1024), 0, s, B);      // the bounds serve every scale
     hipLaunchKernelGGL(grid_setup_kernel, dim3(B.nsets), dim3(64), 0, s, B, bx_ball_div());
     hipLaunchKernelGGL(cell_count_kernel, dim3(nb4k, B.nsets), dim3(1024), 0, s, B);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(ntile, B.nsets), dim3(256), 0, s, B);
@@ -729,13 +749,15 @@ int bxk_ball_grids(bx_ctx* c, hipStream_t s, const float* const* clouds, const i
 }
 
 // Candidate piece tables of keypoints [k0, k0 + K) of every prepared set (one launch); kpts: per cloud, the whole keypoint array.
-int bxk_ball_rows(bx_ctx* c, hipStream_t s, const float* const* kpts, int nclouds, int S, int k0, int K)
+int bxk_ball_rows(bx_ctx* c, hipStream_t s, const float* const* kpts, int nclouds, int S, int k0, int K, int i0, int ni)
 {
     if (K <= 0) return BX_OK;
+    if (ni < 0) ni = S - i0;
+    if (i0 < 0 || ni < 1 || i0 + ni > S) { bx_set_error("bxk_ball_rows: scales [%d, %d) of %d", i0, i0 + ni, S); return BX_ERR_ARG; }
     if (k0 < 0 || (size_t)(k0 + K) > c->ball_st_num) { bx_set_error("bxk_ball_rows: keypoints [%d, %d) exceed the table", k0, k0 + K); return BX_ERR_ARG; }
     BallBatch B;
     batch_from_ctx(c, B);
-    B.S = S; B.nsets = nclouds * S; B.K = K;
+    B.S = S; B.nsets = nclouds * ni; B.K = K; B.i0 = i0; B.ni = ni; B.skip = c->skip;
     for (int cl = 0; cl < nclouds; ++cl) B.kpts[cl] = kpts[cl] + (size_t)k0 * 3;
     for (int i = 0; i < S; ++i) B.logpw[i] = c->ball_logpw[i];
     B.ptab += (size_t)k0 * NPMAX;       // the same shift inside every set

@@ -1,3 +1,10 @@
+// tools/experimental/k_patch_rounds.hip -- NOT part of the library (round-4 experiment, kept for the record).  patch_features_kernel with
+// the voxel query in ROUNDS of 64 list entries per row, two voxels per lane (packed-f32 tests against a broadcast candidate), six rows
+// per wave and round, rows re-packed every round (PF_ROUNDS = 1).  Bit-exact (tests/test_gpu_stages.py, test_gpu_pipeline.py pass with
+// it) and ~45 % fewer query instructions, but SLOWER: 375 / 356 / 289 us per launch at the three scales against 282 / 263 / 222 us for
+// the three-rows-per-wave form with the same hit recording (K = 5000, P = 1024, tools/bench_stage.py patch): only four of the eight
+// waves have work in a round and every round ends in a workgroup barrier, so the patch holds its LDS longer.
+// To try it again: copy over buffer-x_amd/csrc/k_patch.hip and build with tools/build_variant.sh.
 // k_patch.hip -- patch -> cylindrical voxel features, fused:
 //   axis_align   (reference models/patch_embedder.py:122-148; utils/common.py:709-726 cal_Z_axis,
 //                 :501-525 RodsRotatFormula, :111-114 l2_norm)
@@ -13,12 +20,24 @@
 //   patch_features_kernel  one 512-thread workgroup per patch: the patch lives in LDS (16 B/point: x, y, z, and the
 //                          cylindrical radius); candidate lists per (shell, elevation) row by ballot compaction; a
 //                          wave owns 3 rows (60 voxels) and scans the rows' lists 8 candidates per step with LDS
-//                          broadcast reads (the next step's list entries are fetched a step ahead, a step's eight
-//                          points are requested together); a hit is kept as its list position; mask, azimuth
-//                          de-rotation, 3->16 conv + ReLU and the max in registers.
+//                          broadcast reads; mask, azimuth de-rotation, 3->16 conv + ReLU and the max in registers.
 // Output: feat [K][rad][ele*azi][16] in chunk-slot order (bx_chunk_slot).
 #include "bx_common.h"
 #include <cstdlib>
+
+// experiment switches (tools/build_variant.sh): all on in the shipped build
+#ifndef PF_POS
+#define PF_POS 1      // a hit is recorded as its POSITION in the row list (one add instead of an 8-way select); looked up when sampled
+#endif
+#ifndef PF_MAX3
+#define PF_MAX3 1     // ReLU + running max as max(mx, acc, 0) (v_max3_f32)
+#endif
+#ifndef PF_ADDC
+#define PF_ADDC 1     // hit bits shifted in by add-with-carry (candidate j -> bit j, candidates tested 7..0)
+#endif
+#ifndef PF_ROUNDS
+#define PF_ROUNDS 1   // the query in rounds of PF_SEG list entries, two voxels per lane, six rows per wave
+#endif
 
 namespace {
 constexpr int PF_THREADS = 512;
@@ -26,6 +45,13 @@ constexpr int PF_WAVES = PF_THREADS / 64;
 constexpr int MAX_NS = 16;
 constexpr int NROWS = BX_RAD * BX_ELE;                 // 21 (shell, elevation) rows of BX_AZI voxels
 constexpr int RPW = (NROWS + PF_WAVES - 1) / PF_WAVES;   // candidate-list rows built per wave (3)
+constexpr int PF_SEG = 64;                              // list entries of a row scanned per query round
+constexpr int PF_LPR = BX_AZI / 2;                      // query lanes per row: a lane tests the voxels at azimuths a and a + 10
+constexpr int PF_RPW = 64 / PF_LPR;                     // rows per wave and query round (6)
+static_assert(NROWS == 21 && BX_AZI == 20, "PF_ORDER and the two-voxel query are written for the 3 x 7 x 20 voxel grid");
+// the (shell, elevation) rows by expected scan length: the sparse rows around the equator of the outer shells (long lists, never full)
+// first, the short sparse rows next, the dense inner-shell rows (full after a few steps) last
+__device__ const unsigned char PF_ORDER[NROWS] = {17, 10, 9, 16, 11, 18, 8, 15, 12, 19, 7, 13, 14, 20, 0, 1, 2, 3, 4, 5, 6};
 
 __global__ __launch_bounds__(256) void patch_axis_kernel(const float* __restrict__ patches, int K, int P, float* __restrict__ R_out,
                                                          const int32_t* __restrict__ skip)
@@ -105,10 +131,12 @@ __global__ __launch_bounds__(PF_THREADS) void patch_features_kernel(
 #define PF_TR(k) do { if (tr) td[k] = __builtin_readcyclecounter() - t0; } while (0)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* sp = reinterpret_cast<float4*>(smem);                             // [P + 1] x, y, z, sqrt(x^2 + y^2); entry P = a point far away
-    unsigned short* shit = reinterpret_cast<unsigned short*>(sp + P + 1);    // [nsample][BX_VOX] list positions of the hits (+ 4 entries when nsample is odd: 16-byte lists)
+    unsigned short* shit = reinterpret_cast<unsigned short*>(sp + P + 1);    // [nsample][BX_VOX] (+ 4 when nsample is odd: 16-byte lists)
     int* rlen = reinterpret_cast<int*>(shit + (((size_t)nsample * BX_VOX + 7) & ~(size_t)7));   // [32] candidates per (shell, elevation) row
     unsigned short* rlist = reinterpret_cast<unsigned short*>(rlen + 32);    // [NROWS][cap] candidate point indices, ascending
     unsigned short* far8 = rlist + (size_t)NROWS * cap + 8;                   // eight copies of index P (behind the 16-byte read slack)
+    unsigned char* vcnt = reinterpret_cast<unsigned char*>(far8 + 8);         // [BX_VOX (-> 448)] hits recorded per voxel
+    int* rowfull = reinterpret_cast<int*>(vcnt + 448);                        // [32] every voxel of the row has its nsample hits
 
     const int q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -138,6 +166,8 @@ __global__ __launch_bounds__(PF_THREADS) void patch_features_kernel(
     // the far point: a list entry P never passes the distance test, so list tails and idle lanes need no per-candidate bounds checks
     if (tid == 0) sp[P] = make_float4(1.0e30f, 1.0e30f, 1.0e30f, 1.0e30f);
     if (tid < 8) far8[tid] = (unsigned short)P;
+    if (tid < 448) vcnt[tid] = 0;
+    if (tid < 32) rowfull[tid] = 0;
     __syncthreads();
     PF_TR(1);
 
@@ -199,14 +229,107 @@ __global__ __launch_bounds__(PF_THREADS) void patch_features_kernel(
     __syncthreads();
     PF_TR(2);
 
+#if PF_ROUNDS
+    // ---- voxel query in ROUNDS of PF_SEG list entries per row.  A lane tests TWO voxels of one row (azimuths a and a + 10) against the
+    //      row's candidates -- the packed-f32 VALU ops take the candidate's coordinate as a broadcast operand, so a (candidate, voxel)
+    //      test costs half the instructions, LDS reads and index unpacking of the one-voxel form -- and a wave holds up to 6 rows (10
+    //      lanes each).  A round hands the wave 6 of the rows that still have unscanned candidates AND an unfilled voxel, in a static
+    //      order that puts rows of similar scan length together (sparse outer rows first), so lanes whose row is done do not ride along
+    //      with the longest row of a fixed group: the rounds after the first hold only the long rows, packed.  The hit count of a
+    //      voxel lives in LDS between rounds; hits are appended in list order because a row's segments are scanned in round order.
+    {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const int grp = lane / PF_LPR, sub = lane - grp * PF_LPR;       // grp 0..5 = a row of this round, 6 = lanes 60..63 (idle)
+        const int my_row = lane < NROWS ? (int)PF_ORDER[lane] : 0;
+        for (int round = 0; ; ++round) {
+            const int start = round * PF_SEG;
+            bool actl = false;
+            if (lane < NROWS) {
+                const int l_ = rlen[my_row];
+                actl = start < (l_ < 0 ? P : l_) && rowfull[my_row] == 0;
+            }
+            unsigned m = (unsigned)__ballot(actl);                      // the same value in every wave
+            if (m == 0u) break;
+            if (wave * PF_RPW < __popc(m)) {
+                for (int i = 0; i < wave * PF_RPW; ++i) m &= m - 1u;    // scalar: skip the rows of the waves before this one
+                int slot = -1;
+#pragma unroll
+                for (int g = 0; g < PF_RPW; ++g) {
+                    const int b_ = m != 0u ? __ffs((int)m) - 1 : -1;
+                    m &= m - 1u;
+                    slot = grp == g ? b_ : slot;
+                }
+                const bool act = slot >= 0;
+                const int row = __shfl(my_row, act ? slot : 0);
+                const int l_ = rlen[row];
+                const bool direct = l_ < 0;                              // the list overflowed: the row is scanned over the patch itself
+                const int L = direct ? P : ((l_ + 7) & ~7);              // lists are padded to a multiple of 8 with the far point
+                const int end = act ? min(L, start + PF_SEG) : 0;
+                const int v0 = row * BX_AZI + sub, v1 = v0 + PF_LPR;
+                f2 qx = {0.f, 0.f}, qy = {0.f, 0.f}, qz = {0.f, 0.f};
+                int c0 = nsample, c1 = nsample;
+                if (act) {
+                    qx = f2{centres[v0 * 3], centres[v1 * 3]};
+                    qy = f2{centres[v0 * 3 + 1], centres[v1 * 3 + 1]};
+                    qz = f2{centres[v0 * 3 + 2], centres[v1 * 3 + 2]};
+                    c0 = vcnt[v0]; c1 = vcnt[v1];
+                }
+                const unsigned short* rl = rlist + (size_t)row * cap;
+                // the hits of a step in list order, as positions in the list (point indices for a directly scanned row)
+#define PF_RECORD(hm, cnt, v)                                                  \
+                while (hm != 0u && cnt < nsample) {                             \
+                    const int j_ = __ffs((int)hm) - 1;                          \
+                    shit[cnt * BX_VOX + v] = (unsigned short)(i0 + j_);         \
+                    ++cnt;                                                      \
+                    hm &= hm - 1u;                                              \
+                }
+                const bool anyd = __any(direct && act);
+                for (int i0 = start; ; i0 += 8) {
+                    const bool live = i0 < end && (c0 < nsample || c1 < nsample);
+                    if (!__any(live)) break;
+                    // a lane that is done reads eight far points: no per-candidate bounds checks
+                    const uint4 kq = *reinterpret_cast<const uint4*>(live && !direct ? rl + i0 : far8);
+                    int ks[8];
+                    ks[0] = kq.x & 0xffff; ks[1] = kq.x >> 16; ks[2] = kq.y & 0xffff; ks[3] = kq.y >> 16;
+                    ks[4] = kq.z & 0xffff; ks[5] = kq.z >> 16; ks[6] = kq.w & 0xffff; ks[7] = kq.w >> 16;
+                    if (anyd) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ks[j] = (direct && live) ? min(i0 + j, P) : ks[j];
+                    }
+                    unsigned hm0 = 0, hm1 = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float4 d = sp[ks[j]];
+                        const f2 dx = qx - d.x, dy = qy - d.y, dz = qz - d.z;
+                        const f2 dd = (dx * dx + dy * dy) + dz * dz;
+                        if (dd.x < vr2) hm0 |= 1u << j;
+                        if (dd.y < vr2) hm1 |= 1u << j;
+                    }
+                    PF_RECORD(hm0, c0, v0)
+                    PF_RECORD(hm1, c1, v1)
+                }
+#undef PF_RECORD
+                if (act) { vcnt[v0] = (unsigned char)c0; vcnt[v1] = (unsigned char)c1; }
+                // a row whose 20 voxels are full is out of the later rounds
+                const unsigned long long fb = __ballot(c0 >= nsample && c1 >= nsample);
+                if (act && sub == 0 && ((fb >> (grp * PF_LPR)) & ((1ULL << PF_LPR) - 1ULL)) == ((1ULL << PF_LPR) - 1ULL)) rowfull[row] = 1;
+            }
+            __syncthreads();
+        }
+    }
+    PF_TR(3);
+#endif
+#if !PF_ROUNDS
     // ---- voxel query: a wave owns 3 whole rows (60 voxels, lanes 60..63 idle); lanes of one row read the same list
     //      entries and the same points (LDS broadcast), 8 candidates per step so that the dependent LDS reads of a step
     //      overlap; each lane tests its own centre and keeps the first `nsample` hits (ascending point order)
+#endif
     for (int task = wave; task < NROWS / 3; task += PF_WAVES) {
         const int rsub = lane / BX_AZI;                   // 0..2, 3 for the idle lanes
         const bool act = rsub < 3;
         const int row = task * 3 + (act ? rsub : 0);
         const int v = row * BX_AZI + (lane - rsub * BX_AZI);
+#if !PF_ROUNDS
         float qx = 0.f, qy = 0.f, qz = 0.f;
         if (act) { qx = centres[v * 3]; qy = centres[v * 3 + 1]; qz = centres[v * 3 + 2]; }
         const int rl_len = rlen[row];
@@ -214,42 +337,57 @@ __global__ __launch_bounds__(PF_THREADS) void patch_features_kernel(
         const int len = act ? (full ? P : rl_len) : 0;
         const unsigned short* rl = rlist + (size_t)row * cap;
         int cnt = 0;
-        // the hits of a step in list order, up to nsample, as POSITIONS in the row's list (the point index itself for a row scanned over
-        // the whole patch): one add per hit; the point index is looked up when the hit is sampled
-#define PF_RECORD(hm)                                                           \
+        // the hits of a step, in list order, up to nsample (a macro: a lambda taking ks[] by reference sends the array to scratch)
+#if PF_POS
+#define PF_RECORD(hm, ks)                                                       \
         while (hm != 0u && cnt < nsample) {                                     \
             const int j_ = __ffs((int)hm) - 1;                                  \
             shit[cnt * BX_VOX + v] = (unsigned short)(i0 + j_);                 \
             ++cnt;                                                              \
             hm &= hm - 1u;                                                      \
         }
+#else
+#define PF_RECORD(hm, ks)                                                       \
+        while (hm != 0u && cnt < nsample) {                                     \
+            const int j_ = __ffs((int)hm) - 1;                                  \
+            int k_ = ks[0];                                                     \
+            _Pragma("unroll") for (int u = 1; u < 8; ++u) k_ = (j_ == u) ? ks[u] : k_; \
+            shit[cnt * BX_VOX + v] = (unsigned short)k_;                        \
+            ++cnt;                                                              \
+            hm &= hm - 1u;                                                      \
+        }
+#endif
         if (!__any(full)) {
             // the common case: every row of the wave has a list.  Lists are padded with the far point and a lane whose list has
-            // ended reads eight far points, so a candidate costs its index unpack, one LDS read, the distance and one compare.
-            // The slowest wave of the workgroup decides how long the patch holds its LDS, so the step is laid out for latency: the
-            // list entries of step n + 1 are requested before step n computes, and the eight points of a step are requested together.
-            uint4 kq = *reinterpret_cast<const uint4*>(0 < len ? rl : far8);
+            // ended reads eight far points, so a candidate costs its index unpack, one LDS read, the distance and one compare
             for (int i0 = 0; ; i0 += 8) {
                 if (__all(cnt >= nsample || i0 >= len)) break;
+                const uint4 kq = *reinterpret_cast<const uint4*>(i0 < len ? rl + i0 : far8);
                 int ks[8];
                 ks[0] = kq.x & 0xffff; ks[1] = kq.x >> 16; ks[2] = kq.y & 0xffff; ks[3] = kq.y >> 16;
                 ks[4] = kq.z & 0xffff; ks[5] = kq.z >> 16; ks[6] = kq.w & 0xffff; ks[7] = kq.w >> 16;
-                float4 d[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) d[j] = sp[ks[j]];
-                kq = *reinterpret_cast<const uint4*>(i0 + 8 < len ? rl + i0 + 8 : far8);
-                __builtin_amdgcn_sched_barrier(0);
+                unsigned hm = 0;
+#if PF_ADDC
                 float dd[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float dx = qx - d[j].x, dy = qy - d[j].y, dz = qz - d[j].z;
+                    const float4 d = sp[ks[j]];
+                    const float dx = qx - d.x, dy = qy - d.y, dz = qz - d.z;
                     dd[j] = (dx * dx + dy * dy) + dz * dz;
                 }
-                unsigned hm = 0;
 #pragma unroll
-                for (int j = 7; j >= 0; --j)      // hm = 2 hm + (dd < vr2) by add-with-carry: candidate j ends at bit j
+                for (int j = 7; j >= 0; --j)      // hm = 2 hm + (dd < vr2): candidate j ends at bit j
                     asm("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hm) : "v"(dd[j]), "v"(vr2) : "vcc");
-                PF_RECORD(hm)
+#else
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4 d = sp[ks[j]];
+                    const float dx = qx - d.x, dy = qy - d.y, dz = qz - d.z;
+                    const float dd = (dx * dx + dy * dy) + dz * dz;
+                    if (dd < vr2) hm |= 1u << j;
+                }
+#endif
+                PF_RECORD(hm, ks)
             }
         } else {
             for (int i0 = 0; ; i0 += 8) {
@@ -263,24 +401,38 @@ __global__ __launch_bounds__(PF_THREADS) void patch_features_kernel(
                 for (int j = 0; j < 8; ++j) {
                     int k = full ? i0 + j : ks[j];
                     k = k < P ? k : P - 1;
+                    ks[j] = k;
                     const float4 d = sp[k];
                     const float dx = qx - d.x, dy = qy - d.y, dz = qz - d.z;
                     const float dd = (dx * dx + dy * dy) + dz * dz;
                     if (dd < vr2 && i0 + j < len) hm |= 1u << j;
                 }
-                PF_RECORD(hm)
+                PF_RECORD(hm, ks)
             }
         }
 #undef PF_RECORD
         PF_TR(3);
+#else
+        const int rl_len = rlen[row];
+        const bool full = rl_len < 0;
+        const unsigned short* rl = rlist + (size_t)row * cap;
+        const int cnt = act ? (int)vcnt[v] : 0;
+#endif
         if (!act) continue;
         const int a = v % BX_AZI;
         const float r00 = rot[a * 4], r01 = rot[a * 4 + 1], r10 = rot[a * 4 + 2], r11 = rot[a * 4 + 3];
+#if PF_POS
+        // a recorded hit is a position in the row's list (the point index itself for a row scanned over the whole patch)
 #define PF_HIT(j) (full ? (int)shit[(j) * BX_VOX + v] : (int)rl[shit[(j) * BX_VOX + v]])
+#else
+#define PF_HIT(j) ((int)shit[(j) * BX_VOX + v])
+#endif
         const int first = cnt > 0 ? PF_HIT(0) : 0;
         float mx[16];
+#if PF_MAX3
 #pragma unroll
         for (int c = 0; c < 16; ++c) mx[c] = 0.0f;         // ReLU outputs are >= +0: a running max that starts at +0 is the same max
+#endif
         for (int j = 0; j < nsample; ++j) {
             int id = j < cnt ? PF_HIT(j) : first;
             float mask = (j > 0 && id == first) ? 1.0f : 0.0f;
@@ -296,7 +448,12 @@ __global__ __launch_bounds__(PF_THREADS) void patch_features_kernel(
                 acc = fmaf(pnt_w[c * 3 + 0], nx, acc);
                 acc = fmaf(pnt_w[c * 3 + 1], ny, acc);
                 acc = fmaf(pnt_w[c * 3 + 2], z, acc);
-                mx[c] = fmaxf(fmaxf(mx[c], acc), 0.0f);    // ReLU and running max in one v_max3_f32
+#if PF_MAX3
+                mx[c] = fmaxf(fmaxf(mx[c], acc), 0.0f);
+#else
+                acc = acc > 0.0f ? acc : 0.0f;
+                mx[c] = (j == 0 || acc > mx[c]) ? acc : mx[c];
+#endif
             }
         }
         const int s = v / BX_EA, pos = v % BX_EA;
@@ -316,7 +473,8 @@ int bxk_patch_features(bx_ctx* c, hipStream_t s, const float* patches, int K, in
     const int ns = c->p.voxel_sample;
     if (ns < 1 || ns > MAX_NS || P < 2 || P > 8192) { bx_set_error("bxk_patch_features: voxel_sample=%d P=%d unsupported", ns, P); return BX_ERR_ARG; }
     int cap = ((P / 2 + 7) / 8) * 8 + 8;                      // row-list capacity (multiple of 8, one 16-byte read of slack)
-    size_t lds = (size_t)(P + 1) * 16 + (((size_t)ns * BX_VOX + 7) & ~(size_t)7) * 2 + 128 + (size_t)NROWS * cap * 2 + 16 + 16;   // + far point, + far8
+    size_t lds = (size_t)(P + 1) * 16 + (((size_t)ns * BX_VOX + 7) & ~(size_t)7) * 2 + 128 + (size_t)NROWS * cap * 2 + 16 + 16   // + far point, + far8
+                 + 448 + 128;                                                                                                    // + vcnt, rowfull
     if (lds > 160 * 1024) { bx_set_error("bxk_patch_features: P=%d needs %zu B of LDS", P, lds); return BX_ERR_ARG; }
     if (lds > 64 * 1024 && !c->patch_attr_set) {
         BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(patch_features_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
