@@ -59,6 +59,9 @@ CASES = {
     "headline_cfg1_b": ("3DMatch", "indoor_shared", 36885, 103, dict(num_fps=5000, num_points_per_patch=1024, sub_stride=256, row_stride=4)),
     "headline_cfg1_c": ("3DMatch", "indoor_shared", 28334, 112, dict(num_fps=5000, num_points_per_patch=1024, sub_stride=256, row_stride=4)),
     "kitti_cfg2_b": ("KITTI", "kitti_full", 0, 101, dict(num_fps=5000, num_points_per_patch=1024, sub_stride=256, row_stride=4)),
+    # round 4: a 3DLoMatch-like pair at the REAL size (the low-overlap half of BASELINE configs[3]: 20 % overlap, the reference's 3DLoMatch
+    # configuration): few keypoints coincide, the consensus set is small
+    "headline_lo": ("3DLoMatch", "indoor_shared_lo20", 35000, 120, dict(num_fps=5000, num_points_per_patch=1024, sub_stride=256, row_stride=4)),
     # round 4: more pairs at a size where matching is no longer sparse (1 000 - 1 500 keypoints on 4 000 - 6 000-point fragments: a quarter of
     # the keypoints coincide, so the pairs REGISTER with the seeded random weights; 3 scales, the reference's own defaults otherwise), other
     # seeds / densities, so that "F(4x4, 3x3) keeps the reference's mutual and consensus sets" rests on more than three real-size pairs;
@@ -89,6 +92,8 @@ def case_inputs(name):
         pair = bufferx_amd.synth.make_pair(seed, "indoor", n_target=n)
     elif kind == "indoor_shared":
         pair = bufferx_amd.synth.make_pair(seed, "indoor", n_target=n, shared=True)
+    elif kind == "indoor_shared_lo20":
+        pair = bufferx_amd.synth.make_pair(seed, "indoor", n_target=n, shared=True, overlap=0.2)
     elif kind == "indoor_shared_low":
         pair = bufferx_amd.synth.make_pair(seed, "indoor", n_target=n, shared=True, overlap=0.3)
     elif kind == "outdoor_mid":
