@@ -34,6 +34,9 @@ BIG = {
     "headline_cfg1_b": ("3DMatch", dict(), dict(), ("shared", 103, 36885)),
     "headline_cfg1_c": ("3DMatch", dict(), dict(), ("shared", 112, 28334)),
     "kitti_cfg2_b": ("KITTI", dict(), dict(), ("kitti", 101, 0)),
+    # a 3DLoMatch-like pair at the real size (20 % overlap, the reference's 3DLoMatch configuration): it does NOT register -- the consensus
+    # set sits on the 180-degree twin of the near-symmetric room -- and the reference's (wrong) answer has to be reproduced all the same
+    "headline_lo": ("3DLoMatch", dict(), dict(), ("shared_lo20", 120, 35000)),
 }
 BIG = {k: v for k, v in BIG.items() if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", k + ".npz"))}
 
@@ -61,6 +64,8 @@ def big_case(bx, name):
         cfg.match[k] = v
     if kind == "shared":
         pair = bx.synth.make_pair(seed, "indoor", n_target=n, shared=True)
+    elif kind == "shared_lo20":
+        pair = bx.synth.make_pair(seed, "indoor", n_target=n, shared=True, overlap=0.2)
     elif kind == "kitti":
         pair = bx.synth.make_pair(seed, "outdoor", voxel=0.02)
     else:
@@ -222,6 +227,11 @@ def test_headline_pair_registers(headline, bx):
     config/outdoor_config.py:36-37)"""
     cfg = headline["cfg"]
     rre, rte = bx.synth.pose_error(headline["plain"][0], headline["pair"]["T_gt"])
+    if headline["name"] == "headline_lo":
+        # the 20 %-overlap pair is NOT registered, by the reference either (tests/golden/headline_lo.npz: RRE 179.83 deg -- the consensus
+        # set sits on the 180-degree twin of the near-symmetric synthetic room); the same wrong answer is the requirement here
+        assert rre > 170.0, (rre, rte)
+        return
     assert rre < cfg.test.rre_thresh and rte < cfg.test.rte_thresh, (rre, rte, headline["plain"][1])
 
 
