@@ -1,0 +1,366 @@
+// tools/experimental/k_patch_split3.hip -- NOT part of the library (round-4 experiment, kept for the record).  patch_features_kernel with the
+// three rows that have the longest candidate lists at every scale split into two halves scanned by two lane groups of one wave (static task
+// table, second-half hits in a buffer of their own, joined when the voxel is sampled): the longest row of a patch is half as long and all
+// eight waves have a task.  Bit-exact; 279 -> 259 us per launch at the 5 % scale, but 257 -> 274 and 222 -> 234 us at the 2 % and 0.5 %
+// scales (K = 5000, P = 1024): no gain over the three launches of a cloud.  Not kept.
+// k_patch.hip -- patch -> cylindrical voxel features, fused:
+//   axis_align   (reference models/patch_embedder.py:122-148; utils/common.py:709-726 cal_Z_axis,
+//                 :501-525 RodsRotatFormula, :111-114 l2_norm)
+//   normalize    (models/patch_embedder.py:167-170)
+//   SPT          (models/patch_embedder.py:150-165; utils/common.py:431-469 sphere_query, :472-498 var_to_invar)
+//   pnt_layer + max over the voxel samples (models/patch_embedder.py:26-30, 73-77)
+// The reference materialises [K,P,3] x4 temporaries, a [K,420,10,3] gather, the constant voxel grid and 20
+// rotation matrices per call.  Two kernels here:
+//   patch_axis_kernel      one WAVE per patch: 3x3 covariance (lane-strided fmaf partials + xor butterfly, the
+//                          arithmetic contract's "wave order"), binary64 Jacobi eigenvector, Rodrigues -> R [K][9].
+//                          The Jacobi is a ~40k-cycle serial chain; as its own kernel with 32 waves per CU it is
+//                          hidden by parallelism instead of stalling the other waves of a patch's workgroup.
+//   patch_features_kernel  one 512-thread workgroup per patch: the patch lives in LDS (16 B/point: x, y, z, and the
+//                          cylindrical radius); candidate lists per (shell, elevation) row by ballot compaction; a
+//                          wave owns 3 rows (60 voxels) and scans the rows' lists 8 candidates per step with LDS
+//                          broadcast reads (the next step's list entries are fetched a step ahead, a step's eight
+//                          points are requested together); a hit is kept as its list position; mask, azimuth
+//                          de-rotation, 3->16 conv + ReLU and the max in registers.
+// Output: feat [K][rad][ele*azi][16] in chunk-slot order (bx_chunk_slot).
+#include "bx_common.h"
+#include <cstdlib>
+
+namespace {
+constexpr int PF_THREADS = 512;
+constexpr int PF_WAVES = PF_THREADS / 64;
+constexpr int MAX_NS = 16;
+constexpr int NROWS = BX_RAD * BX_ELE;                 // 21 (shell, elevation) rows of BX_AZI voxels
+constexpr int RPW = (NROWS + PF_WAVES - 1) / PF_WAVES;   // candidate-list rows built per wave (3)
+// query tasks: 8 waves x 3 row slots = 24 slots for the 21 rows.  The three rows with the longest candidate lists at every scale -- the
+// equators of the two outer shells, (shell 2, elevation 3), (1, 3), (1, 2) -- take TWO slots each in one wave: lanes 0..19 scan the first
+// half of the list, lanes 20..39 the second half into a buffer of their own, and the halves are joined when the voxel is sampled.  The
+// slowest wave decides how long a patch holds its LDS (three patches per CU); its longest row is now half as long.
+__device__ const unsigned char PF_TASK_ROW[PF_WAVES][3] = {{17, 17, 13}, {10, 10, 14}, {9, 9, 20}, {16, 11, 18}, {8, 15, 12}, {19, 7, 0}, {1, 2, 3}, {4, 5, 6}};
+constexpr int PF_NSPLIT = 3;                            // waves 0 .. PF_NSPLIT - 1 hold a split row in their slots 0 (first half) and 1 (second half)
+static_assert(NROWS == 21 && PF_WAVES == 8, "PF_TASK_ROW is written for 21 rows on 8 waves");
+
+__global__ __launch_bounds__(256) void patch_axis_kernel(const float* __restrict__ patches, int K, int P, float* __restrict__ R_out,
+                                                         const int32_t* __restrict__ skip)
+{
+    if (skip && *skip) return;
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= K) return;
+    const float* pp = patches + (size_t)q * P * 3;
+    const float cx = pp[(size_t)(P - 1) * 3], cy = pp[(size_t)(P - 1) * 3 + 1], cz = pp[(size_t)(P - 1) * 3 + 2];
+    float c00 = 0.f, c01 = 0.f, c02 = 0.f, c11 = 0.f, c12 = 0.f, c22 = 0.f;
+    for (int i = lane; i < P; i += 64) {
+        const float dx = pp[(size_t)i * 3] - cx, dy = pp[(size_t)i * 3 + 1] - cy, dz = pp[(size_t)i * 3 + 2] - cz;
+        c00 = fmaf(dx, dx, c00); c01 = fmaf(dx, dy, c01); c02 = fmaf(dx, dz, c02);
+        c11 = fmaf(dy, dy, c11); c12 = fmaf(dy, dz, c12); c22 = fmaf(dz, dz, c22);
+    }
+    c00 = bx_wave_sum(c00); c01 = bx_wave_sum(c01); c02 = bx_wave_sum(c02);
+    c11 = bx_wave_sum(c11); c12 = bx_wave_sum(c12); c22 = bx_wave_sum(c22);
+    double A[9] = {(double)c00, (double)c01, (double)c02, (double)c01, (double)c11, (double)c12,
+                   (double)c02, (double)c12, (double)c22};
+    double V[9], w[3];
+    bxd_jacobi3(A, V, w);
+    int mi = 0;
+    double mv = fabs(w[0]);
+    if (fabs(w[1]) < mv) { mv = fabs(w[1]); mi = 1; }
+    if (fabs(w[2]) < mv) { mv = fabs(w[2]); mi = 2; }
+    float z0 = (float)(mi == 0 ? V[0] : (mi == 1 ? V[1] : V[2]));
+    float z1 = (float)(mi == 0 ? V[3] : (mi == 1 ? V[4] : V[5]));
+    float z2 = (float)(mi == 0 ? V[6] : (mi == 1 ? V[7] : V[8]));
+    float sdot = ((-z0) * cx + (-z1) * cy) + (-z2) * cz;
+    if (sdot < 0.0f) { z0 = -z0; z1 = -z1; z2 = -z2; }
+    float nz = sqrtf((z0 * z0 + z1 * z1) + z2 * z2);
+    z0 = z0 / nz; z1 = z1 / nz; z2 = z2 / nz;
+    float c0 = z1, c1 = -z0, c2 = 0.0f;
+    float na = sqrtf((z0 * z0 + z1 * z1) + z2 * z2);
+    float nae = na > 1e-8f ? na : 1e-8f;
+    float cosv = z2 / nae;
+    float theta = (float)bxd_acos((double)cosv);
+    double sd, cd;
+    bxd_sincos((double)theta, &sd, &cd);
+    float sn = (float)sd, cs = (float)cd;
+    float nc = sqrtf((c0 * c0 + c1 * c1) + c2 * c2);
+    float nce = nc > 1e-12f ? nc : 1e-12f;
+    c0 = c0 / nce; c1 = c1 / nce; c2 = c2 / nce;
+    float Rx[9] = {0.0f, -c2, c1, c2, 0.0f, -c0, -c1, c0, 0.0f};
+    float Rx2[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            Rx2[i * 3 + j] = fmaf(Rx[i * 3 + 2], Rx[2 * 3 + j], fmaf(Rx[i * 3 + 1], Rx[1 * 3 + j], Rx[i * 3 + 0] * Rx[0 * 3 + j]));
+    float omc = 1.0f - cs;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float I = (i == j) ? 1.0f : 0.0f;
+                float rr = (I + sn * Rx[i * 3 + j]) + omc * Rx2[i * 3 + j];
+                R_out[(size_t)q * 9 + j * 3 + i] = rr;  // transpose(-1,-2)
+            }
+    }
+}
+
+__global__ __launch_bounds__(PF_THREADS) void patch_features_kernel(
+    const float* __restrict__ patches, int K, int P, const double* __restrict__ radius, int aligned,
+    const float* __restrict__ centres, const float* __restrict__ rowc, const float* __restrict__ rot, int nsample, float voxel_r,
+    const float* __restrict__ pnt_w, const float* __restrict__ pnt_b, float* __restrict__ R_out, float* __restrict__ feat,
+    const int32_t* __restrict__ skip, int cap, long long* __restrict__ dbg)
+{
+    if (skip && *skip) return;
+    // optional cycle stamps (BX_BALL_DEBUG): {t0, normalised, row lists, query of wave 0, conv+store of wave 0}
+    long long t0 = 0;
+    const bool tr = dbg != nullptr && (blockIdx.x % 79) == 0 && blockIdx.x / 79 < 60 && threadIdx.x == 0;
+    long long* td = dbg + (blockIdx.x / 79) * 8;
+    if (tr) { t0 = __builtin_readcyclecounter(); td[0] = t0; }
+#define PF_TR(k) do { if (tr) td[k] = __builtin_readcyclecounter() - t0; } while (0)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* sp = reinterpret_cast<float4*>(smem);                             // [P + 1] x, y, z, sqrt(x^2 + y^2); entry P = a point far away
+    unsigned short* shit = reinterpret_cast<unsigned short*>(sp + P + 1);    // [nsample][BX_VOX] list positions of the hits (+ 4 entries when nsample is odd: 16-byte lists)
+    int* rlen = reinterpret_cast<int*>(shit + (((size_t)nsample * BX_VOX + 7) & ~(size_t)7));   // [32] candidates per (shell, elevation) row
+    unsigned short* rlist = reinterpret_cast<unsigned short*>(rlen + 32);    // [NROWS][cap] candidate point indices, ascending
+    unsigned short* far8 = rlist + (size_t)NROWS * cap + 8;                   // eight copies of index P (behind the 16-byte read slack)
+    unsigned short* shitb = far8 + 8;                                         // [nsample][PF_NSPLIT * BX_AZI] hits of the second halves of the split rows
+    unsigned char* cntb = reinterpret_cast<unsigned char*>(shitb + (size_t)nsample * PF_NSPLIT * BX_AZI);   // [64] their counts
+
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* pp = patches + (size_t)q * P * 3;
+    const float des_r = (float)(*radius);
+    const float cx = pp[(size_t)(P - 1) * 3], cy = pp[(size_t)(P - 1) * 3 + 1], cz = pp[(size_t)(P - 1) * 3 + 2];
+    float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+    if (!aligned) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = R_out[(size_t)q * 9 + i];
+    } else if (tid < 9) {
+        R_out[(size_t)q * 9 + tid] = (tid % 4 == 0) ? 1.0f : 0.0f;
+    }
+
+    // ---- centre on the keypoint, rotate (delta @ R), normalise by the scale radius
+    for (int i = tid; i < P; i += PF_THREADS) {
+        const float x = pp[(size_t)i * 3] - cx, y = pp[(size_t)i * 3 + 1] - cy, z = pp[(size_t)i * 3 + 2] - cz;
+        float nx = x, ny = y, nzc = z;
+        if (!aligned) {
+            nx = fmaf(z, R[6], fmaf(y, R[3], x * R[0]));
+            ny = fmaf(z, R[7], fmaf(y, R[4], x * R[1]));
+            nzc = fmaf(z, R[8], fmaf(y, R[5], x * R[2]));
+        }
+        const float px = nx / des_r, py = ny / des_r;
+        sp[i] = make_float4(px, py, nzc / des_r, sqrtf(px * px + py * py));
+    }
+    // the far point: a list entry P never passes the distance test, so list tails and idle lanes need no per-candidate bounds checks
+    if (tid == 0) sp[P] = make_float4(1.0e30f, 1.0e30f, 1.0e30f, 1.0e30f);
+    if (tid < 8) far8[tid] = (unsigned short)P;
+    __syncthreads();
+    PF_TR(1);
+
+    const float vr2 = voxel_r * voxel_r;
+
+    // ---- candidate lists per (shell, elevation) row.  The 20 voxel centres of a row lie on the circle {radius R_c,
+    //      height z_c}; a point can only be within voxel_r of one of them if its distance to that CIRCLE is, i.e.
+    //      (R_p - R_c)^2 + (p_z - z_c)^2 < voxel_r^2 (exact inequality; a 1e-4 margin covers fp32 rounding and the
+    //      fp32-rounded centres).  A wave builds the lists of its (up to 3) rows in one sweep over the patch with
+    //      ballot compaction, so a list is in ascending point order and "the first voxel_sample hits in patch order"
+    //      is simply a scan of the row's list.
+    {
+        const float cthr = vr2 * 1.0001f + 1.0e-6f;
+        float Rc[RPW], zc[RPW];
+        int base[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int row = wave + r * PF_WAVES;
+            Rc[r] = row < NROWS ? rowc[row * 2] : 1.0e30f;     // rows beyond the table never pass
+            zc[r] = row < NROWS ? rowc[row * 2 + 1] : 0.f;
+            base[r] = 0;
+        }
+        for (int k0 = 0; k0 < P; k0 += 64) {
+            const int k = k0 + lane;
+            float4 d = make_float4(0.f, 0.f, 1.0e30f, 0.f);
+            if (k < P) d = sp[k];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int row = wave + r * PF_WAVES;
+                if (row >= NROWS) continue;                  // wave-uniform: waves 5..7 own two rows
+                const float t1 = d.w - Rc[r], t2 = d.z - zc[r];
+                const bool pass = (t1 * t1 + t2 * t2) < cthr;
+                const unsigned long long m = __ballot(pass);
+                // base + the number of passing lanes below this one (v_mbcnt_lo / _hi carry the base in)
+                const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)base[r]));
+                if (pass && pos < cap) rlist[(size_t)row * cap + pos] = (unsigned short)k;
+                base[r] += __popcll(m);
+            }
+        }
+        // a row with more candidates than its list holds (rare: e.g. the padded points at the keypoint for the inner
+        // shell) is scanned over the whole patch instead: len = -1
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int row = wave + r * PF_WAVES;
+                if (row < NROWS) rlen[row] = base[r] <= cap ? base[r] : -1;
+            }
+        }
+        // pad every list to a multiple of 8 entries with the far point (cap is a multiple of 8)
+        if (lane < 8) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int row = wave + r * PF_WAVES;
+                if (row < NROWS && base[r] <= cap && base[r] + lane < ((base[r] + 7) & ~7))
+                    rlist[(size_t)row * cap + base[r] + lane] = (unsigned short)P;
+            }
+        }
+    }
+    __syncthreads();
+    PF_TR(2);
+
+    // ---- voxel query: a wave owns 3 row slots (60 voxels, lanes 60..63 idle); lanes of one slot read the same list entries and the
+    //      same points (LDS broadcast), 8 candidates per step so that the dependent LDS reads of a step overlap; each lane tests its own
+    //      centre and keeps the first `nsample` hits of its slot's part of the list (ascending point order)
+    {
+        const int task = wave;
+        const int rsub = lane / BX_AZI;                   // 0..2, 3 for the idle lanes
+        const bool act = rsub < 3;
+        const int row = PF_TASK_ROW[task][act ? rsub : 0];
+        const int az = lane - rsub * BX_AZI;
+        const int v = row * BX_AZI + az;
+        const bool split = task < PF_NSPLIT && rsub < 2;  // this slot holds half of a split row
+        const bool second = split && rsub == 1;
+        float qx = 0.f, qy = 0.f, qz = 0.f;
+        if (act) { qx = centres[v * 3]; qy = centres[v * 3 + 1]; qz = centres[v * 3 + 2]; }
+        const int rl_len = rlen[row];
+        const bool full = rl_len < 0;
+        const int L = full ? P : rl_len;
+        const int half = ((L >> 1) + 7) & ~7;             // lists are padded to a multiple of 8: so is the first half
+        const int start = second ? (half < L ? half : L) : 0;
+        const int len = act ? (split && !second ? (half < L ? half : L) : L) - start : 0;       // entries of this slot's part
+        const unsigned short* rl = rlist + (size_t)row * cap;
+        const unsigned short* rls = rl + start;
+        unsigned short* hdst = second ? shitb + task * BX_AZI + az : shit + v;                   // hit j of the slot at hdst[j * hstride]
+        const int hstride = second ? PF_NSPLIT * BX_AZI : BX_VOX;
+        int cnt = 0;
+        // the hits of a step in list order, up to nsample, as POSITIONS in the row's list (the point index itself for a row scanned over
+        // the whole patch): two adds per hit; the point index is looked up when the hit is sampled
+#define PF_RECORD(hm)                                                           \
+        while (hm != 0u && cnt < nsample) {                                     \
+            const int j_ = __ffs((int)hm) - 1;                                  \
+            hdst[cnt * hstride] = (unsigned short)(start + i0 + j_);            \
+            ++cnt;                                                              \
+            hm &= hm - 1u;                                                      \
+        }
+        if (!__any(full)) {
+            // the common case: every row of the wave has a list.  Lists are padded with the far point and a lane whose list has
+            // ended reads eight far points, so a candidate costs its index unpack, one LDS read, the distance and one compare.
+            // The list entries of step n + 1 are requested before step n computes, and the eight points of a step are requested together.
+            uint4 kq = *reinterpret_cast<const uint4*>(0 < len ? rls : far8);
+            for (int i0 = 0; ; i0 += 8) {
+                if (__all(cnt >= nsample || i0 >= len)) break;
+                int ks[8];
+                ks[0] = kq.x & 0xffff; ks[1] = kq.x >> 16; ks[2] = kq.y & 0xffff; ks[3] = kq.y >> 16;
+                ks[4] = kq.z & 0xffff; ks[5] = kq.z >> 16; ks[6] = kq.w & 0xffff; ks[7] = kq.w >> 16;
+                float4 d[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] = sp[ks[j]];
+                kq = *reinterpret_cast<const uint4*>(i0 + 8 < len ? rls + i0 + 8 : far8);
+                __builtin_amdgcn_sched_barrier(0);
+                float dd[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float dx = qx - d[j].x, dy = qy - d[j].y, dz = qz - d[j].z;
+                    dd[j] = (dx * dx + dy * dy) + dz * dz;
+                }
+                unsigned hm = 0;
+#pragma unroll
+                for (int j = 7; j >= 0; --j)      // hm = 2 hm + (dd < vr2) by add-with-carry: candidate j ends at bit j
+                    asm("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hm) : "v"(dd[j]), "v"(vr2) : "vcc");
+                PF_RECORD(hm)
+            }
+        } else {
+            for (int i0 = 0; ; i0 += 8) {
+                if (__all(cnt >= nsample || i0 >= len)) break;
+                const uint4 kq = *reinterpret_cast<const uint4*>(i0 < len && !full ? rls + i0 : far8);
+                int ks[8];
+                ks[0] = kq.x & 0xffff; ks[1] = kq.x >> 16; ks[2] = kq.y & 0xffff; ks[3] = kq.y >> 16;
+                ks[4] = kq.z & 0xffff; ks[5] = kq.z >> 16; ks[6] = kq.w & 0xffff; ks[7] = kq.w >> 16;
+                unsigned hm = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    int k = full ? start + i0 + j : ks[j];
+                    k = k < P ? k : P;                      // the far point
+                    const float4 d = sp[k];
+                    const float dx = qx - d.x, dy = qy - d.y, dz = qz - d.z;
+                    const float dd = (dx * dx + dy * dy) + dz * dz;
+                    if (dd < vr2 && i0 + j < len) hm |= 1u << j;
+                }
+                PF_RECORD(hm)
+            }
+        }
+#undef PF_RECORD
+        PF_TR(3);
+        // the second half of a split row hands its hits to the lane of the first half (same wave: LDS operations of a wave complete in order)
+        if (second) cntb[task * BX_AZI + az] = (unsigned char)cnt;
+        if (!act || second) return;
+        const int a = az;
+        const float r00 = rot[a * 4], r01 = rot[a * 4 + 1], r10 = rot[a * 4 + 2], r11 = rot[a * 4 + 3];
+        const int cnta = cnt;
+        if (split) {
+            const int cb = (int)cntb[task * BX_AZI + az];
+            cnt = cnta + cb < nsample ? cnta + cb : nsample;
+        }
+        const unsigned short* hb = shitb + task * BX_AZI + az;
+#define PF_POSN(j) ((j) < cnta ? (int)shit[(j) * BX_VOX + v] : (int)hb[((j) - cnta) * (PF_NSPLIT * BX_AZI)])
+#define PF_HIT(j) (full ? PF_POSN(j) : (int)rl[PF_POSN(j)])
+        const int first = cnt > 0 ? PF_HIT(0) : 0;
+        float mx[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) mx[c] = 0.0f;         // ReLU outputs are >= +0: a running max that starts at +0 is the same max
+        for (int j = 0; j < nsample; ++j) {
+            int id = j < cnt ? PF_HIT(j) : first;
+            float mask = (j > 0 && id == first) ? 1.0f : 0.0f;
+            if (j == 0 && first == 0) mask = 1.0f;
+            float om = 1.0f - mask;
+            float4 d = sp[id];
+            float x = d.x * om, y = d.y * om, z = d.z * om;
+            float nx = fmaf(y, r01, x * r00);
+            float ny = fmaf(y, r11, x * r10);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                float acc = pnt_b[c];
+                acc = fmaf(pnt_w[c * 3 + 0], nx, acc);
+                acc = fmaf(pnt_w[c * 3 + 1], ny, acc);
+                acc = fmaf(pnt_w[c * 3 + 2], z, acc);
+                mx[c] = fmaxf(fmaxf(mx[c], acc), 0.0f);    // ReLU and running max in one v_max3_f32
+            }
+        }
+        const int s = v / BX_EA, pos = v % BX_EA;
+        float4* fo = reinterpret_cast<float4*>(feat + (((size_t)q * BX_RAD + s) * BX_EA + pos) * 16);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fo[u] = make_float4(mx[u], mx[4 + u], mx[8 + u], mx[12 + u]);
+        PF_TR(4);
+#undef PF_HIT
+#undef PF_POSN
+    }
+}
+}  // namespace
+
+int bxk_patch_features(bx_ctx* c, hipStream_t s, const float* patches, int K, int P, const double* radius, int aligned,
+                       float* R_out, float* feat_out)
+{
+    if (K <= 0) return BX_OK;
+    const int ns = c->p.voxel_sample;
+    if (ns < 1 || ns > MAX_NS || P < 2 || P > 8192) { bx_set_error("bxk_patch_features: voxel_sample=%d P=%d unsupported", ns, P); return BX_ERR_ARG; }
+    int cap = ((P / 2 + 7) / 8) * 8 + 8;                      // row-list capacity (multiple of 8, one 16-byte read of slack)
+    size_t lds = (size_t)(P + 1) * 16 + (((size_t)ns * BX_VOX + 7) & ~(size_t)7) * 2 + 128 + (size_t)NROWS * cap * 2 + 16 + 16   // + far point, + far8
+                 + (size_t)ns * PF_NSPLIT * BX_AZI * 2 + 64;                                                                      // + second-half hits, counts
+    if (lds > 160 * 1024) { bx_set_error("bxk_patch_features: P=%d needs %zu B of LDS", P, lds); return BX_ERR_ARG; }
+    if (lds > 64 * 1024 && !c->patch_attr_set) {
+        BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(patch_features_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        c->patch_attr_set = 1;
+    }
+    const float voxel_r = (float)(c->p.delta / (double)c->p.rad_n);
+    if (!aligned) hipLaunchKernelGGL(patch_axis_kernel, dim3((K + 3) / 4), dim3(256), 0, s, patches, K, P, R_out, c->skip);
+    hipLaunchKernelGGL(patch_features_kernel, dim3(K), dim3(PF_THREADS), lds, s, patches, K, P, radius, aligned, c->d_centres,
+                       c->d_rowc, c->d_rot, ns, voxel_r, c->d_pnt_w, c->d_pnt_b, R_out, feat_out, c->skip, cap,
+                       getenv("BX_BALL_DEBUG") ? c->ball_dbg : nullptr);
+    BX_LAUNCH_CHECK();
+    return BX_OK;
+}
