@@ -126,7 +126,7 @@ def test_oracle_matches_reference_at_real_size(bx, packed, golden_dir, name):
     RANSAC inliers and consensus count identical; per-scale mutual sets as (source keypoint, target keypoint) correspondences with at most
     3 differing per scale (a keypoint whose patch holds a point within an ulp of a radius / voxel bound: the reference's torch / numpy
     arithmetic and the contract may decide differently -- zero on five of the seven fixtures); consensus set identical as correspondences;
-    pose within 1e-4 deg / 1e-4 m; >= 99.6 % of the sampled descriptor rows within 2e-5.  (The GPU twin of this test runs in every
+    pose within 1e-4 deg / 1e-4 m; >= 99 % of the sampled descriptor rows of every (scale, cloud) within 2e-5.  (The GPU twin of this test runs in every
     `pytest -m gpu`: tests/test_gpu_headline.py::test_headline_vs_reference.)"""
     from oracle import pipeline as PL
     from test_gpu_headline import big_case
@@ -141,7 +141,7 @@ def test_oracle_matches_reference_at_real_size(bx, packed, golden_dir, name):
         assert cap[f"s{i}_des_r"] == pytest.approx(float(g["des_r"][i]), abs=1e-12)
         for c in ("src", "tgt"):
             d = np.abs(cap[f"s{i}_{c}_desc"][::rs].astype(np.float64) - g[f"s{i}_{c}_desc"]).max(1)
-            assert (d < 2e-5).mean() >= 0.996
+            assert (d < 2e-5).mean() >= 0.99
         a_ = set(zip(cap[f"s{i}_s_mids"].tolist(), cap[f"s{i}_t_mids"].tolist()))
         b_ = set(zip(g[f"s{i}_s_mids"].tolist(), g[f"s{i}_t_mids"].tolist()))
         assert len(a_ ^ b_) <= 3, (name, i, sorted(a_ ^ b_))
