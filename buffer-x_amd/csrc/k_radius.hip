@@ -12,7 +12,10 @@ namespace {
 constexpr int NB = 8194;  // bins 0..8192 = smallest m with d2 < thr[m]; 8193 = beyond max_r
 
 // threshold m of the bisection grid, fp32((5 m / 8192)^2) exactly as the host table d_rad_thr holds it: recomputed (two exact
-// binary64 products, one rounding) instead of loaded -- the two dependent loads per distance were what the kernel waited for
+// binary64 products, one rounding) instead of loaded -- the two dependent loads per distance were what the kernel waited for.
+// (Round 4: the all-fp32 form (float)m * (5.0f / 8192.0f) squared is the same number for every m -- checked exhaustively -- and was
+// measured 26-35 % SLOWER, 387 / 413 vs 306 us per launch; 16-bit LDS counters, two per word, for eight instead of four resident
+// workgroups per CU: 306 vs 312 us.  Neither kept; tests/test_gpu_stages.py::test_radius_concentrated_bins stays.)
 __device__ __forceinline__ float thr_of(int m)
 {
     const double r = 5.0 * (double)m / 8192.0;

@@ -26,6 +26,14 @@ def ctx(bx, packed):
     c.close()
 
 
+@pytest.fixture(scope="module")
+def ctx_big(bx, packed):
+    from bufferx_amd import lib
+    c = lib.Context(_cfg(bx, K=256, P=128, S=2, nk=256), max_points=140000, device=0, packed_weights=packed)
+    yield c
+    c.close()
+
+
 def _np(t):
     return t.detach().cpu().numpy()
 
@@ -90,6 +98,22 @@ def test_radius(ctx, oracle, bx):
     thr = [5, 2, 0.5]
     got = _np(ctx.radius(pts, len(pts), kp, thr))
     ref = [oracle.radius(pts, len(pts), kp, t) for t in thr]
+    assert np.array_equal(got, np.array(ref))
+
+
+@pytest.mark.parametrize("n", [40000, 51000, 130000])
+def test_radius_concentrated_bins(ctx_big, oracle, n):
+    """radius_hist_kernel under the worst concentration of its histogram: a cloud that is four point masses, so every (keypoint, point)
+    distance falls into a handful of the 8 193 bins (tens of thousands of LDS atomics of a workgroup on one address; distances that sit
+    exactly on bin thresholds)"""
+    rng = np.random.default_rng(n)
+    sites = np.array([[0, 0, 0], [0.8, 0.1, 0], [0.2, 1.3, 0.4], [2.0, 2.0, 1.0]], np.float32)
+    pts = sites[rng.integers(0, 4, n)]
+    pts[:17] += rng.normal(0, 0.05, (17, 3)).astype(np.float32)      # a few points off the masses
+    kp = np.ascontiguousarray(pts[rng.permutation(n)[:128]])
+    thr = [5, 2, 0.5]
+    got = _np(ctx_big.radius(pts, n, kp, thr))
+    ref = [oracle.radius(pts, n, kp, t) for t in thr]
     assert np.array_equal(got, np.array(ref))
 
 
