@@ -34,6 +34,9 @@
 #include <cstdlib>
 #include <vector>
 
+#ifndef BX_W43_EARLYREQ
+#define BX_W43_EARLYREQ 1          // slab pieces of the next chunk requested BEFORE the transform and written late in the MFMA loop (0: the round-4 first form)
+#endif
 #ifndef BX_W43_STAMP
 #define BX_W43_STAMP 0             // 1: instrumented build (tools/build_variant.sh): s_memtime phase stamps of workgroup (0, 0) into bx_debug_read
 #endif
@@ -196,11 +199,13 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
 #pragma unroll
     for (int q = 0; q < NLD; ++q) lwrite1(q);
     bool st_live = lg < ngroups;
+#if !BX_W43_EARLYREQ
     if (st_live) {
 #pragma unroll
         for (int q = 0; q < NLD; ++q) gload1(q, lg, lc);
         ladv();
     }
+#endif
 #if BX_W43_STAMP
     // phase stamps (instrumented build only), cycles summed over the kernel: 0 MFMA phase (incl. the slab traffic inside it), 2 barrier A,
     // 3 transform + V stores, 4 barrier B, 5 (unused), 6 = groups, 7 output transform
@@ -222,14 +227,31 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
             BX_STAMP(0);
             __syncthreads();         // the slab of this chunk is complete; every wave is done with the V planes of the chunk before
             BX_STAMP(2);
+#if BX_W43_EARLYREQ
+            // the pieces of the NEXT chunk are requested here, a transform and nine planes before they are written to the slab: loads
+            // and the weight ring share one in-order counter, so a request issued between ring loads (the first form: planes 2, 4, 6, 8)
+            // held the plane three ahead until the HBM access returned
+            st_live = lg < ngroups;
+            const bool st_was = st_live;
+            if (st_live) {
+#pragma unroll
+                for (int q = 0; q < NLD; ++q) gload1(q, lg, lc);
+                ladv();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int lgq = 0, lcq = 0;
+            (void)lgq; (void)lcq;
+#endif
             transform();
             BX_STAMP(3);
             __syncthreads();         // V complete; the slab is free
             BX_STAMP(4);
+#if !BX_W43_EARLYREQ
             const bool st_was = st_live;
             st_live = lg < ngroups;
             const int lgq = lg, lcq = lc;
             if (st_live) ladv();
+#endif
             if (cw) {
                 const int cn = cc + 1 == NCHUNK ? 0 : cc + 1;
                 f32x4 ar[3];
@@ -244,11 +266,15 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
                         // ONE compute wave per SIMD: four back-to-back MFMAs on one accumulator would issue at the 40-cycle dependent
                         // latency instead of every 32 cycles (with two waves per SIMD the sibling fills the gap), so the two row tiles
                         // of the plane alternate
+#if BX_W43_EARLYREQ
+                        if (p >= NPH - 2 * NLD - 1 && p < NPH - 1 && ((p - (NPH - 2 * NLD - 1)) & 1) == 0) { if (st_was) lwrite1((p - (NPH - 2 * NLD - 1)) >> 1); }
+#else
                         if (p >= 1 && p < 1 + 2 * NLD) {
                             const int q = (p - 1) >> 1;
                             if (((p - 1) & 1) == 0) { if (st_was) lwrite1(q); }
                             else if (st_live) gload1(q, lgq, lcq);
                         }
+#endif
                         const f32x4 a0 = ar[0], a1 = ar[1];
                         if (p + 1 < NPH) {
                             ar[0] = *reinterpret_cast<const f32x4*>(abase + (((p + 1) * VR4) * ROWF) * 4);
@@ -268,11 +294,15 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
                     }
                     // the slab is free during the MFMA phase: piece q goes to the slab behind plane 2 q + 1 (requested a whole chunk ago),
                     // its register is re-requested behind plane 2 q + 2
+#if BX_W43_EARLYREQ
+                    if (p >= NPH - 2 * NLD - 1 && p < NPH - 1 && ((p - (NPH - 2 * NLD - 1)) & 1) == 0) { if (st_was) lwrite1((p - (NPH - 2 * NLD - 1)) >> 1); }
+#else
                     if (p >= 1 && p < 1 + 2 * NLD) {
                         const int q = (p - 1) >> 1;
                         if (((p - 1) & 1) == 0) { if (st_was) lwrite1(q); }
                         else if (st_live) gload1(q, lgq, lcq);
                     }
+#endif
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int rt = 0; rt < RT4; ++rt) {
@@ -290,7 +320,9 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
 #pragma unroll
                 for (int q = 0; q < NLD; ++q) {
                     if (st_was) lwrite1(q);
+#if !BX_W43_EARLYREQ
                     if (st_live) gload1(q, lgq, lcq);
+#endif
                 }
             }
         }

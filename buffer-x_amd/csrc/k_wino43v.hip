@@ -137,11 +137,6 @@ __global__ __launch_bounds__(CT, 2) void wino43v_kernel(const float* __restrict_
 #pragma unroll
     for (int q = 0; q < NLD; ++q) lwrite1(q);
     bool st_live = lg < ngroups;
-    if (st_live) {
-#pragma unroll
-        for (int q = 0; q < NLD; ++q) gload1(q, lg, lc);
-        ladv();
-    }
 
     float4* ex = reinterpret_cast<float4*>(Vp);             // output exchange [wave][8][lane]
     float4* mine = ex + (wave * 8) * 64 + lane;
@@ -156,12 +151,17 @@ __global__ __launch_bounds__(CT, 2) void wino43v_kernel(const float* __restrict_
 #pragma unroll 1
         for (int cc = 0; cc < NE; ++cc) {
             __syncthreads();         // the slab of this chunk is complete; every wave is done with the V planes of the chunk before
+            // the pieces of the NEXT chunk are requested here, a transform and several planes before they are written to the slab (loads and
+            // the weight ring share one in-order counter: a request between ring loads holds the plane three ahead until it returns)
+            st_live = lg < ngroups;
+            if (st_live) {
+#pragma unroll
+                for (int q = 0; q < NLD; ++q) gload1(q, lg, lc);
+                ladv();
+            }
+            __builtin_amdgcn_sched_barrier(0);
             transform();
             __syncthreads();         // V complete; the slab is free
-            const bool st_was = st_live;
-            st_live = lg < ngroups;
-            const int lgq = lg, lcq = lc;
-            if (st_live) ladv();
             const int cn = cc + 1 == NE ? 0 : cc + 1;
             f32x4 ar[3];
             ar[0] = *reinterpret_cast<const f32x4*>(abase);
@@ -170,11 +170,8 @@ __global__ __launch_bounds__(CT, 2) void wino43v_kernel(const float* __restrict_
             for (int p = 0; p < NPH; ++p) {
                 const float4 bqq = bring[p % 3];
                 bring[p % 3] = p + 3 < NPH ? bload(cc * NPL + p + 3) : bload(cn * NPL + p + 3 - NPH);
-                if (p >= 1 && p < 1 + 2 * NLD) {    // slab traffic inside the MFMA phase: piece q written behind plane 2 q + 1, re-requested behind 2 q + 2
-                    const int q = (p - 1) >> 1;
-                    if (((p - 1) & 1) == 0) { if (st_was) lwrite1(q); }
-                    else if (st_live) gload1(q, lgq, lcq);
-                }
+                // slab writes inside the MFMA phase, late: piece q behind plane NPH - 2 NLD - 1 + 2 q
+                if (p >= NPH - 2 * NLD - 1 && p < NPH - 1 && ((p - (NPH - 2 * NLD - 1)) & 1) == 0) { if (st_live) lwrite1((p - (NPH - 2 * NLD - 1)) >> 1); }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int rt = 0; rt < RT4; ++rt) {
