@@ -228,7 +228,7 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
             __syncthreads();         // the slab of this chunk is complete; every wave is done with the V planes of the chunk before
             BX_STAMP(2);
 #if BX_W43_EARLYREQ
-            // the pieces of the NEXT chunk are requested here, a transform and nine planes before they are written to the slab: loads
+            // the pieces of the NEXT chunk are requested here, a transform and a whole MFMA phase before they are written to the slab: loads
             // and the weight ring share one in-order counter, so a request issued between ring loads (the first form: planes 2, 4, 6, 8)
             // held the plane three ahead until the HBM access returned
             st_live = lg < ngroups;
@@ -266,9 +266,7 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
                         // ONE compute wave per SIMD: four back-to-back MFMAs on one accumulator would issue at the 40-cycle dependent
                         // latency instead of every 32 cycles (with two waves per SIMD the sibling fills the gap), so the two row tiles
                         // of the plane alternate
-#if BX_W43_EARLYREQ
-                        if (p >= NPH - 2 * NLD - 1 && p < NPH - 1 && ((p - (NPH - 2 * NLD - 1)) & 1) == 0) { if (st_was) lwrite1((p - (NPH - 2 * NLD - 1)) >> 1); }
-#else
+#if !BX_W43_EARLYREQ
                         if (p >= 1 && p < 1 + 2 * NLD) {
                             const int q = (p - 1) >> 1;
                             if (((p - 1) & 1) == 0) { if (st_was) lwrite1(q); }
@@ -294,9 +292,7 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
                     }
                     // the slab is free during the MFMA phase: piece q goes to the slab behind plane 2 q + 1 (requested a whole chunk ago),
                     // its register is re-requested behind plane 2 q + 2
-#if BX_W43_EARLYREQ
-                    if (p >= NPH - 2 * NLD - 1 && p < NPH - 1 && ((p - (NPH - 2 * NLD - 1)) & 1) == 0) { if (st_was) lwrite1((p - (NPH - 2 * NLD - 1)) >> 1); }
-#else
+#if !BX_W43_EARLYREQ
                     if (p >= 1 && p < 1 + 2 * NLD) {
                         const int q = (p - 1) >> 1;
                         if (((p - 1) & 1) == 0) { if (st_was) lwrite1(q); }
@@ -316,6 +312,15 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+#if BX_W43_EARLYREQ
+                // the slab writes of the next chunk, all at once behind the last plane: a slab write must know its piece has arrived, and
+                // with one in-order counter for every load that is a wait for the ring loads in flight too -- one such wait here, under the
+                // tail of the MFMAs, instead of one per piece inside the loop
+                if (st_was) {
+#pragma unroll
+                    for (int q = 0; q < NLD; ++q) lwrite1(q);
+                }
+#endif
             } else {                 // CW = 32: the waves without a column tile carry the slab traffic only
 #pragma unroll
                 for (int q = 0; q < NLD; ++q) {

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(CT, 2) void wino43v_kernel(const float* __restrict_
 #pragma unroll 1
         for (int cc = 0; cc < NE; ++cc) {
             __syncthreads();         // the slab of this chunk is complete; every wave is done with the V planes of the chunk before
-            // the pieces of the NEXT chunk are requested here, a transform and several planes before they are written to the slab (loads and
+            // the pieces of the NEXT chunk are requested here, a transform and a whole MFMA phase before they are written to the slab (loads and
             // the weight ring share one in-order counter: a request between ring loads holds the plane three ahead until it returns)
             st_live = lg < ngroups;
             if (st_live) {
@@ -170,8 +170,6 @@ __global__ __launch_bounds__(CT, 2) void wino43v_kernel(const float* __restrict_
             for (int p = 0; p < NPH; ++p) {
                 const float4 bqq = bring[p % 3];
                 bring[p % 3] = p + 3 < NPH ? bload(cc * NPL + p + 3) : bload(cn * NPL + p + 3 - NPH);
-                // slab writes inside the MFMA phase, late: piece q behind plane NPH - 2 NLD - 1 + 2 q
-                if (p >= NPH - 2 * NLD - 1 && p < NPH - 1 && ((p - (NPH - 2 * NLD - 1)) & 1) == 0) { if (st_live) lwrite1((p - (NPH - 2 * NLD - 1)) >> 1); }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int rt = 0; rt < RT4; ++rt) {
@@ -184,6 +182,11 @@ __global__ __launch_bounds__(CT, 2) void wino43v_kernel(const float* __restrict_
                     acc[p][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bqq.w, a.w, acc[p][rt], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            }
+            // the slab writes of the next chunk, all at once behind the last plane (one wait for the loads in flight instead of one per piece)
+            if (st_live) {
+#pragma unroll
+                for (int q = 0; q < NLD; ++q) lwrite1(q);
             }
         }
         __syncthreads();             // every wave is done with the V planes: their bytes carry the exchange now
