@@ -13,9 +13,11 @@
 //  * workgroup = 8 waves = CW output channels (64; 32 for the two 32-channel layers) of THREE units (30 tile rows = two MFMA row tiles);
 //    compute wave (column tile ct, half) owns the eighteen planes of the xi rows 3 half .. 3 half + 2: 36 accumulator tiles = 144 VGPRs.
 //    With CW = 32 only waves 0..3 (one per SIMD) stream MFMAs; the others still stage and transform.
-//  * slab: the (unit, chunk) maps arrive as 16-byte pieces (four per thread, non-temporal), requested a WHOLE chunk before they are
-//    written to the LDS slab (10 x 22 positions per unit with the wrap-around columns copied and the rows beyond the map left zero),
-//    and both the slab write and the next request sit INSIDE the MFMA loop (one piece per plane): the slab is idle there.
+//  * slab: the (unit, chunk) maps arrive as 16-byte pieces (four per thread, non-temporal) in the LDS slab (10 x 22 positions per unit
+//    with the wrap-around columns copied and the rows beyond the map left zero).  Loads and the weight ring share ONE in-order counter
+//    (vmcnt), so the pieces of the next chunk are requested right after the chunk's first barrier -- a transform and a whole MFMA phase
+//    before they are needed, never between two ring loads -- and written to the slab all at once behind the last plane (the write's
+//    wait for its piece is a wait for every load in flight: one such drain per chunk, under the tail of the MFMAs).
 //  * transform: thread (tile row, channel slot) owns ONE channel of ONE tile: 36 ds_read_b32 from one base register, the column pass
 //    shared by the six xi rows (144 VALU; the round-3 item (xi, tile row, quad) re-read the window once per xi: 253 KB of slab reads
 //    per chunk instead of 69 KB), 36 ds_write_b32 into the V planes.  Slab row pitch 22 x 20 + 4 floats: the two tiles of a 32-lane
