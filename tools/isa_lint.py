@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""tools/isa_lint.py -- compile the two Winograd F(4x4) kernels to gfx950 assembly (no GPU needed) and report, per instantiation, the
+things round 4 found to cost time on this chip because loads, stores and scratch reloads share ONE in-order counter (vmcnt):
+
+  * spilled VGPRs (a reload is a VMEM operation: it waits for everything issued before it, and everything after it waits for it);
+  * scratch reloads BETWEEN the global stores of an output round (each is a drain of the stores in front of it);
+  * `s_waitcnt vmcnt(0)` inside the plane loop (a drain of the weight ring in flight).
+
+  python tools/isa_lint.py            # prints one line per kernel; exit code 1 if a 64-column Cylindrical_Net kernel regresses
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CS = os.path.join(ROOT, "buffer-x_amd", "csrc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + CS,
+         "-S", "--cuda-device-only"]
+
+
+def kernels(asm):
+    """{mangled name: [instruction lines]} of every kernel in an assembly file"""
+    out, cur = {}, None
+    for line in asm.splitlines():
+        m = re.match(r"^(_Z\w+):\s*(;.*)?$", line)
+        if m:
+            cur = m.group(1)
+            out[cur] = []
+        elif line.startswith(".Lfunc_end"):
+            cur = None
+        elif cur is not None and line.startswith("\t") and not line.lstrip().startswith((";", ".")):
+            out[cur].append(line.strip())
+    return out
+
+
+def report(name, ins, spills):
+    stores = [i for i, l in enumerate(ins) if l.startswith("global_store")]
+    between = 0
+    if stores:
+        # output rounds = runs of stores without an s_barrier in between
+        run = [stores[0]]
+        for a, b in zip(stores, stores[1:]):
+            if any(l.startswith("s_barrier") for l in ins[a:b]):
+                between += sum(1 for l in ins[run[0]:run[-1]] if l.startswith("scratch_load"))
+                run = [b]
+            else:
+                run.append(b)
+        between += sum(1 for l in ins[run[0]:run[-1]] if l.startswith("scratch_load"))
+    mf = [i for i, l in enumerate(ins) if l.startswith("v_mfma")]
+    drains = 0
+    if mf:
+        # the plane loop = between the first and the last MFMA of the longest barrier-free run of MFMAs
+        runs, cur = [], [mf[0]]
+        for a, b in zip(mf, mf[1:]):
+            if any(l.startswith("s_barrier") for l in ins[a:b]):
+                runs.append(cur)
+                cur = [b]
+            else:
+                cur.append(b)
+        runs.append(cur)
+        longest = max(runs, key=len)
+        drains = sum(1 for l in ins[longest[0]:longest[-1]] if re.match(r"s_waitcnt\s+vmcnt\(0\)", l))
+    return dict(kernel=name, spilled_vgprs=spills, scratch_reloads_between_output_stores=between, vmcnt0_inside_plane_loop=drains,
+                mfma=len(mf), stores=len(stores))
+
+
+def main():
+    bad = 0
+    for src in ("k_wino43.hip", "k_wino43v.hip"):
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "k.s")
+            subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + ["-o", out, os.path.join(CS, src)], check=True, stderr=subprocess.DEVNULL)
+            asm = open(out).read()
+        spills = dict(zip(re.findall(r"^\s+\.name:\s+(_Z\w+)", asm, re.M), [int(v) for v in re.findall(r"\.vgpr_spill_count:\s+(\d+)", asm)]))
+        for name, ins in kernels(asm).items():
+            if "wino43" not in name:
+                continue
+            short = re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", name)[:48]
+            r = report(short, ins, spills.get(name, -1))
+            print(r)
+            if src == "k_wino43.hip" and "Li64ELi64" in name and (r["scratch_reloads_between_output_stores"] or r["vmcnt0_inside_plane_loop"]):
+                bad += 1
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
