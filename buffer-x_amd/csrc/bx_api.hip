@@ -352,7 +352,7 @@ int pose_stack(bx_ctx* c, hipStream_t s, const float* s_equi, const float* t_equ
                const int32_t* m_dev, int max_m, float* ind, float* logits_out)
 {
     int rc;
-    // layer 0 on the implicit cost volume: the collapsed binary64 form (k_cost.hip) unless BX_COST_L0=direct asks for the fp32 MFMA
+    // layer 0 on the implicit cost volume: the collapsed binary64 form (k_cost.hip) unless bx_params.cost_l0_form = BX_COST_L0_DIRECT asks for the fp32 MFMA
     // convolution of the volume (round-1/2 kernel, kept for A/B measurements; its arithmetic contract is the oracle's "direct" form)
     if (c->cost_direct) rc = bxk_cost_l1(c, s, s_equi, t_equi, s_mids, t_mids, m_dev, max_m, c->act0);
     else rc = bxk_cost_l0(c, s, s_equi, t_equi, s_mids, t_mids, m_dev, max_m, c->act0);

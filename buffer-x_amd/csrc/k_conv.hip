@@ -558,7 +558,12 @@ int launch_conv(bx_ctx* c, int net, int layer, hipStream_t s, const ConvLayerDev
 int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, const int32_t* units_dev, int max_units, float* out)
 {
     constexpr int CYL = (BX_ELE + 2) * (BX_AZI + 2);   // 198 LDS rows per unit: cylindrical map + halo
-    if (net == 0 && c->use_wino == 2) return bxk_wino43(c, s, layer, in, units_dev, max_units, out);      // F(4x4, 3x3): every layer
+    if (max_units < 1) return BX_OK;                   // an empty launch is not an error in any form (bx_desc_net(K = 0), bx_conv_layer(units = 0))
+    if (net == 0 && c->use_wino == 2) {
+        const int rc43 = bxk_wino43(c, s, layer, in, units_dev, max_units, out);                          // F(4x4, 3x3): every layer
+        if (rc43 >= 0) return rc43;
+        // -1 = "not served" (a device-side unit count): the direct kernels below take it
+    }
     if (net == 0 && c->use_wino == 1) {
         const int rcw = bxk_wino(c, s, layer, in, units_dev, max_units, out);                             // F(2x2, 3x3): layers 0..5
         if (rcw >= 0) return rcw;

@@ -49,6 +49,11 @@ def test_world2_records_equal_world1(tmp_path):
         # the roofline fields are fractions of a peak: flops ISSUED on the matrix pipe, never above 1
         assert 0 < j["roofline"]["frac"] <= 1.0 and 0 < j["roofline_costnet"]["frac"] <= 1.0 and j["roofline"]["algorithmic_rate_x_peak"] > 0
         assert j["config"]["arithmetic_forms"] == {"desc_conv": "winograd43", "pose_conv": "winograd43", "cost_l0": "collapsed"}
+        # the line proves from the gathered data that the collective saw every rank (round 5)
+        co = j["collective"]
+        assert co["world_size_seen"] == n and co["ranks_contributing"] == n and co["records"] == j["steps"] * n and co["pair_ids_complete"]
+        assert co["records_per_rank"] == [j["steps"]] * n and 0 < co["rank_pairs_per_s_min"] <= co["rank_pairs_per_s_max"]
+        assert j["p50_ms_per_pair"] == j["p50_ms_per_pair_inflight1"]
     assert j1["registered_ok"] == j2["registered_ok"] == j3["registered_ok"]
     assert j1["host_ms_per_pair"] > 0
     e2e = j1["e2e_pairs_per_s"]          # files -> poses leg (N = 1 only): both RNG modes produce a rate
@@ -73,5 +78,6 @@ def test_world8_on_one_gpu_equals_world1(tmp_path):
     keep = [i for i in range(24) if i != 22]                      # column 22 = model_ms (a measurement)
     assert np.array_equal(a[:, keep], b[:, keep])
     assert j8["n_gpus"] == 8 and j8["registered_ok"] == j1["registered_ok"]
+    assert j8["collective"]["world_size_seen"] == 8 and j8["collective"]["ranks_contributing"] == 8 and j8["collective"]["records_per_rank"] == [2] * 8
     print("\nWORLD8_SAME_GPU", json.dumps({"host_ms_per_pair_world8": j8["host_ms_per_pair"], "host_ms_per_pair_world1": j1["host_ms_per_pair"],
                                           "pairs_per_s_world8_one_gpu": j8["value"], "pairs_per_s_world1": j1["value"]}))

@@ -38,7 +38,18 @@ BIG = {
     # set sits on the 180-degree twin of the near-symmetric room -- and the reference's (wrong) answer has to be reproduced all the same
     "headline_lo": ("3DLoMatch", dict(), dict(), ("shared_lo20", 120, 35000)),
 }
-BIG = {k: v for k, v in BIG.items() if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", k + ".npz"))}
+# Matches that differ from the reference's run, PINNED per fixture at what was observed (profiles/r04_realsize_report.jsonl, re-measured
+# every round): a regression that flips more matches than this fails, on the fixtures that had none as much as on the two that have some.
+PINNED_FLIPS = {"headline_cfg1": 0, "kitti_cfg2": 0, "tiers_early": 0, "headline_cfg1_b": 4, "headline_cfg1_c": 0, "kitti_cfg2_b": 0,
+                "headline_lo": 1}
+assert set(PINNED_FLIPS) == set(BIG)
+
+
+def golden_path(name):
+    """A missing fixture is a FAILURE, not a silently smaller suite (the seven names above are part of the parity claim)."""
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz")
+    assert os.path.exists(p), f"real-size fixture {p} is missing: re-mint it with tests/golden/make_golden.py {name}"
+    return p
 
 
 def _np(t):
@@ -80,6 +91,7 @@ def headline(request, bx, packed, oracle):
     import torch
     from bufferx_amd import lib
     name = request.param
+    golden_path(name)
     cfg, pair, seed = big_case(bx, name)
     ctx = lib.Context(cfg, max_points=max(len(pair["src"]), len(pair["tgt"])), device=0, packed_weights=packed)
     perm = [np.stack([oracle.make_perm(len(pair[k]), seed, 2 * i + c).astype(np.int32) for i in range(S)]) for c, k in enumerate(("src", "tgt"))]
@@ -241,7 +253,7 @@ def test_headline_vs_reference(headline, bx, golden_dir):
     per-scale mutual sets and consensus set, and the pose within the north-star tolerance 1e-4 deg / 1e-4 m.  The number of
     descriptor rows that differ beyond 2e-5 (a point within an ulp of a radius / voxel bound decided differently by the reference's
     torch / numpy arithmetic) is reported AND bounded (0.4 % of the sampled rows): DESIGN.md section 4 quotes it."""
-    g = np.load(os.path.join(golden_dir, headline["name"] + ".npz"))
+    g = np.load(golden_path(headline["name"]))
     pair, used = headline["pair"], headline["used"]
     assert np.array_equal(pair["src"][:8], g["src_head"]) and np.array_equal(pair["tgt"][:8], g["tgt_head"])
     assert (len(pair["src"]), len(pair["tgt"])) == (int(g["n_src"]), int(g["n_tgt"]))
@@ -294,6 +306,7 @@ def test_headline_vs_reference(headline, bx, golden_dir):
         import json
         with open(out, "a") as f:
             f.write(json.dumps({headline["name"]: report}) + "\n")
+    assert flips <= PINNED_FLIPS[headline["name"]], report      # pinned per fixture (zero on five of the seven)
     assert (tup[0], tup[2]) == (int(g["num_inliers"]), int(g["num_inlier_ind"])) and abs(tup[1] - int(g["num_mutual"])) <= flips
     assert cons_o == cons_g, report                # the consensus set as correspondences
     if flips == 0:

@@ -116,6 +116,11 @@ def test_oracle_pipeline_matches_reference(bx, packed, golden_dir, name):
 
 
 # ------------------------------------------------------------------ the real-size fixtures (K = 5000 / P = 1024 / S = 3)
+# smallest fraction of the sampled descriptor rows of one (scale, cloud) within 2e-5 of the reference's, per fixture: the z-aligned
+# configurations agree in every row; the un-aligned (indoor) ones have a few rows per thousand with a point within an ulp of a radius /
+# voxel bound
+BIG_ROWS_MIN_FRAC = {"headline_cfg1": 0.99, "kitti_cfg2": 0.99, "tiers_early": 0.99, "headline_cfg1_b": 0.99, "headline_cfg1_c": 0.99,
+                     "kitti_cfg2_b": 0.99, "headline_lo": 0.99}
 BIG_NAMES = ["headline_cfg1", "kitti_cfg2", "tiers_early", "headline_cfg1_b", "headline_cfg1_c", "kitti_cfg2_b", "headline_lo"]
 
 
@@ -129,19 +134,21 @@ def test_oracle_matches_reference_at_real_size(bx, packed, golden_dir, name):
     pose within 1e-4 deg / 1e-4 m; >= 99 % of the sampled descriptor rows of every (scale, cloud) within 2e-5.  (The GPU twin of this test runs in every
     `pytest -m gpu`: tests/test_gpu_headline.py::test_headline_vs_reference.)"""
     from oracle import pipeline as PL
-    from test_gpu_headline import big_case
-    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    from test_gpu_headline import big_case, golden_path, PINNED_FLIPS
+    g = np.load(golden_path(name))
     cfg, pair, seed = big_case(bx, name)
     cap = {}
     pose, n_inl, n_mut, n_ind, scales = PL.register_pair(pair["src"], pair["tgt"], packed, cfg, pair["aligned_z"], seed, cap)
     assert scales == int(g["scales_used"])
     rs = int(g["row_stride"])
-    flips = 0
+    flips, worst_rows = 0, 1.0
     for i in range(scales):
         assert cap[f"s{i}_des_r"] == pytest.approx(float(g["des_r"][i]), abs=1e-12)
         for c in ("src", "tgt"):
             d = np.abs(cap[f"s{i}_{c}_desc"][::rs].astype(np.float64) - g[f"s{i}_{c}_desc"]).max(1)
-            assert (d < 2e-5).mean() >= 0.99
+            worst_rows = min(worst_rows, float((d < 2e-5).mean()))
+            # pinned per fixture just below what was observed (profiles/r05_big_oracle.jsonl: desc_rows_within_2e5_min_frac)
+            assert (d < 2e-5).mean() >= BIG_ROWS_MIN_FRAC[name]
         a_ = set(zip(cap[f"s{i}_s_mids"].tolist(), cap[f"s{i}_t_mids"].tolist()))
         b_ = set(zip(g[f"s{i}_s_mids"].tolist(), g[f"s{i}_t_mids"].tolist()))
         assert len(a_ ^ b_) <= 3, (name, i, sorted(a_ ^ b_))
@@ -157,4 +164,11 @@ def test_oracle_matches_reference_at_real_size(bx, packed, golden_dir, name):
     assert (n_inl, n_ind) == (int(g["num_inliers"]), int(g["num_inlier_ind"])) and abs(n_mut - int(g["num_mutual"])) <= flips
     rre, rte = bx.synth.pose_difference(np.asarray(pose, np.float64), g["pose"])
     print("\nBIG_ORACLE", name, "flips", flips, "pose diff", rre, rte)
+    out = os.environ.get("BX_BIG_ORACLE_REPORT")
+    if out:
+        import json
+        with open(out, "a") as f:
+            f.write(json.dumps(dict(case=name, matches_that_differ=flips, pinned=PINNED_FLIPS[name], desc_rows_within_2e5_min_frac=worst_rows,
+                                    counts=[n_inl, n_mut, n_ind, scales], pose_diff_deg_m=[rre, rte])) + "\n")
+    assert flips <= PINNED_FLIPS[name]
     assert rre < 1e-4 and rte < 1e-4

@@ -1,86 +1,195 @@
-// micro-benchmark 4: does the VALU / LDS work of ONE wave run under the MFMAs of the OTHER wave of the same SIMD?
-// A workgroup of 8 waves (two per SIMD, 1 workgroup per CU, 256 workgroups): waves 0..3 are "matrix" waves (a stream of independent
-// v_mfma_f32_16x16x4_f32 on two alternating accumulators), waves 4..7 are "vector" waves (the F(4x4) input transform's instruction mix:
-// LDS reads, fmaf chains, LDS writes).  Modes: 1 matrix waves only, 2 vector waves only, 3 both at once.  If the two kinds of work
-// overlap, time(3) ~ max(time(1), time(2)); if a VALU / LDS instruction of the vector wave takes issue time from the matrix wave,
-// time(3) ~ time(1) + time(2).
-//   hipcc --offload-arch=gfx950 -O3 -o mfma_coissue mfma_coissue.hip && ./mfma_coissue
+// micro-benchmark 4 (round 5 rewrite): WHICH instruction classes run under a stream of f32 MFMAs on a gfx950 SIMD, and where?
+//
+// Round 4 measured one mix (LDS reads + fmaf chains + LDS writes in the SIMD's other wave: both / sum = 1.00) and concluded "nothing
+// co-issues".  The review pointed out that hipcc had SLP-packed that "fmaf chain" into v_pk_fma_f32 (the class MI355X_MICROARCH.md
+// lists as an anti-lever beside MFMAs), so the conclusion was not established per class.  This version pins every instruction with
+// inline asm (the ISA is what the source says: check with `llvm-objdump -d`), one row per class:
+//
+//   plain f32 VALU      v_fma_f32, v_add_f32
+//   packed f32 VALU     v_pk_fma_f32, v_pk_add_f32
+//   integer / move VALU v_add_u32, v_xor_b32, v_lshl_add_u32, v_mov_b32
+//   LDS                 ds_read_b32, ds_read_b128, ds_write_b32, ds_write_b128
+//   VMEM                global_load_dword (L1 / L2 resident), global_load_dwordx4
+//   SALU                s_add_u32, s_nop 0
+//
+// in two placements:
+//   SAME  the filler instructions sit in the MFMA wave itself, NF of them behind every v_mfma_f32_16x16x4_f32 (issue interval 32
+//         cycles per SIMD: the guide hides <= 5 single-issue fillers per 32-cycle gap of a bf16 MFMA stream);
+//   OTHER the fillers run in the SIMD's second wave (waves 4..7 of the workgroup; waves 0..3 stream the MFMAs), NF per MFMA-time.
+// One workgroup of 8 waves per CU, 256 workgroups.  For every row three launches: MFMAs only, fillers only, both; loop time =
+// time(2 x iterations) - time(iterations).  Reported per MFMA slot (144 per iteration): cycles from s_memtime of workgroup 0 and
+// the wall-clock ratio both / max(M, F), both / (M + F), and the EXTRA cycles one filler adds to the MFMA stream.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o mfma_coissue mfma_coissue.hip && ./mfma_coissue
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(512, 2) void k(const float* __restrict__ in, float* __restrict__ out, int iters, int mode, int vwork)
+enum { C_FMA, C_ADD, C_PKFMA, C_PKADD, C_IADD, C_XOR, C_LSHLADD, C_MOV, C_DSR32, C_DSR128, C_DSW32, C_DSW128, C_GLD, C_GLD4, C_SALU, C_SNOP, NCLS };
+static const char* CLS_NAME[NCLS] = {"v_fma_f32", "v_add_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_add_u32", "v_xor_b32", "v_lshl_add_u32", "v_mov_b32",
+                                     "ds_read_b32", "ds_read_b128", "ds_write_b32", "ds_write_b128", "global_load_dword", "global_load_dwordx4", "s_add_u32", "s_nop 0"};
+
+struct Regs {
+    float f[8];
+    f32x2 p[4];
+    f32x4 q[4];
+    int i[8];
+    float c1, c2;
+    f32x2 pc1, pc2;
+    unsigned lds;          // byte address of this lane's LDS word
+    unsigned lds16;        // byte address of this lane's 16-byte LDS piece
+    const float* gp;       // this lane's global word (L1 / L2 resident)
+    int s;
+};
+
+template <int CLS>
+__device__ __forceinline__ void filler(Regs& r, int k)
 {
-    __shared__ __attribute__((aligned(16))) float lds[16 * 1024];
-    for (int i = threadIdx.x; i < 16 * 1024; i += blockDim.x) lds[i] = in[i & 1023];
+    if constexpr (CLS == C_FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r.f[k & 7]) : "v"(r.c1), "v"(r.c2));
+    else if constexpr (CLS == C_ADD) asm volatile("v_add_f32 %0, %0, %1" : "+v"(r.f[k & 7]) : "v"(r.c2));
+    else if constexpr (CLS == C_PKFMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(r.p[k & 3]) : "v"(r.pc1), "v"(r.pc2));
+    else if constexpr (CLS == C_PKADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(r.p[k & 3]) : "v"(r.pc2));
+    else if constexpr (CLS == C_IADD) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r.i[k & 7]) : "v"(r.i[(k + 3) & 7]));
+    else if constexpr (CLS == C_XOR) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(r.i[k & 7]) : "v"(r.i[(k + 3) & 7]));
+    else if constexpr (CLS == C_LSHLADD) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(r.i[k & 7]) : "v"(r.i[(k + 3) & 7]));
+    else if constexpr (CLS == C_MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(r.i[k & 7]) : "v"(r.i[(k + 3) & 7]));
+    else if constexpr (CLS == C_DSR32) asm volatile("ds_read_b32 %0, %1" : "+v"(r.f[k & 7]) : "v"(r.lds) : "memory");
+    else if constexpr (CLS == C_DSR128) asm volatile("ds_read_b128 %0, %1" : "+v"(r.q[k & 3]) : "v"(r.lds16) : "memory");
+    else if constexpr (CLS == C_DSW32) asm volatile("ds_write_b32 %0, %1" : : "v"(r.lds), "v"(r.c1) : "memory");
+    else if constexpr (CLS == C_DSW128) asm volatile("ds_write_b128 %0, %1" : : "v"(r.lds16), "v"(r.q[0]) : "memory");
+    else if constexpr (CLS == C_GLD) asm volatile("global_load_dword %0, %1, off" : "+v"(r.f[k & 7]) : "v"(r.gp) : "memory");
+    else if constexpr (CLS == C_GLD4) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(r.q[k & 3]) : "v"(r.gp) : "memory");
+    else if constexpr (CLS == C_SALU) asm volatile("s_add_u32 %0, %0, 1" : "+s"(r.s) : : "scc");
+    else if constexpr (CLS == C_SNOP) asm volatile("s_nop 0");
+}
+
+constexpr int NM = 144;    // MFMA slots per iteration (one chunk of the F(4x4) kernel per wave)
+
+template <int CLS, int NF, bool SAME, bool DO_M, bool DO_F>
+__global__ __launch_bounds__(512, 1) void k(const float* __restrict__ in, float* __restrict__ out, long long* __restrict__ cyc, int iters)
+{
+    __shared__ __attribute__((aligned(16))) float lds[8 * 64 * 4 * 2];
+    for (int i = threadIdx.x; i < 8 * 64 * 4 * 2; i += blockDim.x) lds[i] = in[i & 1023];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float res = 0.f;
-    if (wave < 4) {
-        if (mode & 1) {
-            f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-            const float x = in[lane], y = in[lane + 64];
+    Regs r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { r.f[i] = in[lane + i]; r.i[i] = lane * 7 + i; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.p[i] = (f32x2){in[lane + i], in[lane + 2 * i]};
+    r.q[0] = (f32x4){in[lane], in[lane + 1], in[lane + 2], in[lane + 3]};
+    r.q[1] = r.q[0]; r.q[2] = r.q[0]; r.q[3] = r.q[0];
+    r.c1 = 1.0001f; r.c2 = in[lane + 9] * 1e-3f;
+    r.pc1 = (f32x2){1.0001f, 0.9999f}; r.pc2 = (f32x2){r.c2, r.c2};
+    r.lds = (unsigned)(threadIdx.x * 4);          // the array is the kernel's only LDS object: it starts at LDS address 0
+    r.lds16 = (unsigned)(threadIdx.x * 16);
+    r.gp = in + (threadIdx.x & 1023);
+    r.s = __builtin_amdgcn_readfirstlane(wave);
+    f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    const float x = in[lane], y = in[lane + 64];
+    const bool mwave = wave < 4;
+    long long t0 = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) t0 = __builtin_readcyclecounter();
+    if (SAME) {
+        if (mwave)      // waves 4..7 idle: one wave per SIMD
             for (int it = 0; it < iters; ++it) {
 #pragma unroll
-                for (int u = 0; u < 72; ++u) {              // 144 MFMAs per iteration = one chunk of the F(4x4) kernel per wave
-                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y, x, a1, 0, 0, 0);
+                for (int u = 0; u < NM; ++u) {
+                    if (DO_M) acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, acc[u & 3], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (DO_F) {
+#pragma unroll
+                        for (int kf = 0; kf < NF; ++kf) filler<CLS>(r, u * NF + kf);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             }
-            res = a0.x + a1.y;
-        }
     } else {
-        if (mode & 2) {
-            float* w = lds + (wave - 4) * 4096 + lane;
-            float acc = 0.f;
-            for (int it = 0; it < iters; ++it) {
-                for (int r = 0; r < vwork; ++r) {           // vwork x (36 LDS reads, 144 fmaf, 36 LDS writes) = vwork transform tasks per iteration
-                    float t[36];
+        if (mwave) {
+            if (DO_M)
+                for (int it = 0; it < iters; ++it) {
 #pragma unroll
-                    for (int i = 0; i < 36; ++i) t[i] = w[i * 64];
-#pragma unroll
-                    for (int p = 0; p < 4; ++p)
-#pragma unroll
-                        for (int i = 0; i < 36; ++i) t[i] = fmaf(t[i], 1.0001f, t[(i + 7) % 36]);
-#pragma unroll
-                    for (int i = 0; i < 36; ++i) w[i * 64] = t[i];
-                    acc += t[0];
+                    for (int u = 0; u < NM; ++u) {
+                        acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, acc[u & 3], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
+        } else if (DO_F) {
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int u = 0; u < NM * NF; ++u) filler<CLS>(r, u);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             }
-            res = acc;
         }
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = (long long)__builtin_readcyclecounter() - t0;
+    float res = acc[0].x + acc[1].y + acc[2].z + acc[3].w + r.q[0].x + r.q[1].y + r.q[2].z + r.q[3].w + (float)r.s;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) res += r.f[i] + (float)r.i[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) res += r.p[i].x + r.p[i].y;
     if (res == 12345.678f) out[blockIdx.x * blockDim.x + threadIdx.x] = res;
+}
+
+static float *g_in, *g_out;
+static long long* g_cyc;
+
+template <int CLS, int NF, bool SAME, bool DO_M, bool DO_F>
+static void measure(double& ms, double& cycles)
+{
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    double best[2] = {1e9, 1e9}; long long bc[2] = {0, 0};
+    for (int rep = 0; rep < 4; ++rep)
+        for (int h = 0; h < 2; ++h) {
+            hipEventRecord(a);
+            hipLaunchKernelGGL((k<CLS, NF, SAME, DO_M, DO_F>), dim3(256), dim3(512), 0, 0, g_in, g_out, g_cyc, 100 * (h + 1));
+            hipEventRecord(b); hipEventSynchronize(b);
+            float t; hipEventElapsedTime(&t, a, b);
+            long long c; hipMemcpy(&c, g_cyc, 8, hipMemcpyDeviceToHost);
+            if (rep > 0 && t < best[h]) { best[h] = t; bc[h] = c; }
+        }
+    ms = best[1] - best[0];
+    cycles = (double)(bc[1] - bc[0]) / (100.0 * NM);        // s_memtime ticks per MFMA slot
+    hipEventDestroy(a); hipEventDestroy(b);
+}
+
+static double g_m_ms[2], g_m_cyc[2];     // MFMA-only baselines [SAME]
+
+template <int CLS, int NF, bool SAME>
+static void row()
+{
+    double fm, fc, bm, bcy;
+    measure<CLS, NF, SAME, false, true>(fm, fc);
+    measure<CLS, NF, SAME, true, true>(bm, bcy);
+    const double mm = g_m_ms[SAME], mc = g_m_cyc[SAME];
+    printf("%-20s %-5s NF=%d | MFMA only %6.1f cyc/slot | fillers only %6.1f cyc/slot (%5.2f per filler) | both %6.1f cyc/slot | both/max %.2f both/sum %.2f | extra per filler %+6.2f cyc | wall ms M %.3f F %.3f both %.3f\n",
+           CLS_NAME[CLS], SAME ? "SAME" : "OTHER", NF, mc, fc, fc / NF, bcy, bm / (mm > fm ? mm : fm), bm / (mm + fm), (bcy - mc) / NF, mm, fm, bm);
+    fflush(stdout);
+}
+
+template <int CLS>
+static void cls_rows()
+{
+    row<CLS, 1, true>(); row<CLS, 2, true>(); row<CLS, 4, true>(); row<CLS, 6, true>();
+    row<CLS, 2, false>(); row<CLS, 4, false>(); row<CLS, 8, false>();
 }
 
 int main()
 {
-    float *in, *out;
-    hipMalloc(&in, 4096 * 4); hipMalloc(&out, 256 * 512 * 4);
+    hipMalloc(&g_in, 4096 * 4); hipMalloc(&g_out, 256 * 512 * 4); hipMalloc(&g_cyc, 64);
     std::vector<float> h(4096);
-    for (int i = 0; i < 4096; ++i) h[i] = (float)((i * 37) % 101) * 0.01f;
-    hipMemcpy(in, h.data(), 4096 * 4, hipMemcpyHostToDevice);
-    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    // loop time of 200 iterations = time(400 iterations) - time(200 iterations): launch, LDS fill and tail cancel
-    for (int vwork = 1; vwork <= 4; ++vwork) {
-        double d[4] = {0, 0, 0, 0};
-        for (int mode = 1; mode <= 3; ++mode) {
-            double best[2] = {1e9, 1e9};
-            for (int rep = 0; rep < 5; ++rep)
-                for (int h = 0; h < 2; ++h) {
-                    hipEventRecord(a);
-                    hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, in, out, 200 * (h + 1), mode, vwork);
-                    hipEventRecord(b); hipEventSynchronize(b);
-                    float t; hipEventElapsedTime(&t, a, b);
-                    if (rep > 0 && t < best[h]) best[h] = t;
-                }
-            d[mode] = best[1] - best[0];
-        }
-        // per iteration and SIMD: 144 MFMAs x 32 cycles = 4 608 cycles of the matrix pipe
-        printf("vector work x%d per iteration, 200 iterations: matrix only %.3f ms (%.0f ns / iteration), vector only %.3f ms, both %.3f ms -> both / max = %.2f, both / sum = %.2f\n",
-               vwork, d[1], d[1] * 1e6 / 200, d[2], d[3], d[3] / (d[1] > d[2] ? d[1] : d[2]), d[3] / (d[1] + d[2]));
-    }
+    for (int i = 0; i < 4096; ++i) h[i] = (float)((i * 37) % 101) * 0.01f + 0.5f;
+    hipMemcpy(g_in, h.data(), 4096 * 4, hipMemcpyHostToDevice);
+    measure<C_FMA, 1, true, true, false>(g_m_ms[1], g_m_cyc[1]);
+    measure<C_FMA, 1, false, true, false>(g_m_ms[0], g_m_cyc[0]);
+    printf("# MFMA only: one wave per SIMD (SAME placement) %.2f cyc/MFMA, %.3f ms per 100 x 144; with an idle sibling wave resident (OTHER) %.2f cyc/MFMA, %.3f ms\n",
+           g_m_cyc[1], g_m_ms[1], g_m_cyc[0], g_m_ms[0]);
+    cls_rows<C_FMA>(); cls_rows<C_ADD>(); cls_rows<C_PKFMA>(); cls_rows<C_PKADD>();
+    cls_rows<C_IADD>(); cls_rows<C_XOR>(); cls_rows<C_LSHLADD>(); cls_rows<C_MOV>();
+    cls_rows<C_DSR32>(); cls_rows<C_DSR128>(); cls_rows<C_DSW32>(); cls_rows<C_DSW128>();
+    cls_rows<C_GLD>(); cls_rows<C_GLD4>(); cls_rows<C_SALU>(); cls_rows<C_SNOP>();
     return 0;
 }
