@@ -112,6 +112,7 @@ void carve(bx_ctx* c, char* base, size_t* total)
     c->act0 = cv.take<float>(act);
     c->act1 = cv.take<float>(act);
     c->patches = cv.take<float>(K * P * 3);
+    c->pcnt = cv.take<int32_t>(K);
     c->feat = cv.take<float>(K * BX_RAD * BX_EA * 16);
     c->pts_perm = cv.take<float>(NMAX * 3);
     for (int i = 0; i < 2; ++i) {
@@ -133,6 +134,7 @@ void carve(bx_ctx* c, char* base, size_t* total)
         }
     for (int i = 0; i < 2; ++i) c->fps_td[i] = tiled ? cv.take<float>(NMAX) : nullptr;
     c->patches2 = tiled ? cv.take<float>(K * P * 3) : nullptr;
+    c->pcnt2 = tiled ? cv.take<int32_t>(K) : nullptr;
     c->feat2 = tiled ? cv.take<float>(K * BX_RAD * BX_EA * 16) : nullptr;
     for (int i = 0; i < 2; ++i) c->act2[i] = tiled ? cv.take<float>(K * 8 * BX_EA * 16) : nullptr;   // largest Cylindrical_Net map: 128 channels
     for (int i = 0; i < 2; ++i) c->act3[i] = tiled ? cv.take<float>(K * 8 * BX_EA * 16) : nullptr;
@@ -691,6 +693,25 @@ int bx_ball_group(bx_ctx* c, void* stream, const float* pts_perm, int32_t n, con
     return bxk_ball_group(c, (hipStream_t)stream, pts_perm, n, kpts, K, radius, P, idx_out, patches_out);
 }
 
+int bx_ball_group_counted(bx_ctx* c, void* stream, const float* pts_perm, int32_t n, const float* kpts, int32_t K, const double* radius,
+                          int32_t P, float* patches_out, int32_t* count_out)
+{
+    BX_ENTER(c, false);
+    if (!pts_perm || !kpts || !radius || !patches_out || !count_out) { bx_set_error("bx_ball_group_counted: null argument"); return BX_ERR_ARG; }
+    c->skip = nullptr;
+    c->ball_waves_hint = 0;
+    return bxk_ball_group(c, (hipStream_t)stream, pts_perm, n, kpts, K, radius, P, nullptr, patches_out, count_out);
+}
+
+int bx_patch_features_counted(bx_ctx* c, void* stream, const float* patches, const int32_t* counts, const float* kpts, int32_t K, int32_t P,
+                              const double* radius, int32_t aligned_z, float* R_out, float* feat_out)
+{
+    BX_ENTER(c, true);
+    if (!patches || !counts || !kpts || !radius || !R_out || !feat_out) { bx_set_error("bx_patch_features_counted: null argument"); return BX_ERR_ARG; }
+    c->skip = nullptr;
+    return bxk_patch_features(c, (hipStream_t)stream, patches, K, P, radius, aligned_z, R_out, feat_out, counts, kpts);
+}
+
 int bx_patch_features(bx_ctx* c, void* stream, const float* patches, int32_t K, int32_t P, const double* radius, int32_t aligned_z,
                       float* R_out, float* feat_out)
 {
@@ -920,15 +941,19 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
         const bool side = multi && cl == 1;
         hipStream_t ds = side ? c->tgt_stream : s;
         float* patches = side ? c->patches2 : c->patches;
+        // hit-count hand-over: the query kernel writes only the real slots of a patch and their number, the two patch kernels take the
+        // count (k_ball.hip / k_patch.hip; bit-identical features).  A captured (scale, cloud) keeps the padded form: the capture
+        // buffer holds the reference's [K][P][3] tensor.
+        int32_t* pcnt = capc ? nullptr : (side ? c->pcnt2 : c->pcnt);
         float* feat = side ? c->feat2 : c->feat;
         // expected neighbourhood = threshold % of the cloud: large ones get 4 waves per keypoint, small ones 2 (measured)
         c->ball_waves_hint = p.search_radius_thresholds[i] >= 1.5 ? 4 : 2;
         // the whole-pair path does not need the ball_query index list (nothing downstream reads it): idx_out = nullptr
-        { ProfScope ps(c, ds, 2); if ((rc = bxk_ball_query(c, ds, cl * S + i, ns[cl], c->kpts[cl], k0, kn, &st->des_r[i], P, nullptr, patches)) != BX_OK) return rc; }
+        { ProfScope ps(c, ds, 2); if ((rc = bxk_ball_query(c, ds, cl * S + i, ns[cl], c->kpts[cl], k0, kn, &st->des_r[i], P, nullptr, patches, pcnt)) != BX_OK) return rc; }
         if (capc && c->cap.pts_perm) {      // the permuted cloud is never materialised on the hot path
             if ((rc = bx_permute_launch(ds, clouds[cl], perms[cl] + (size_t)i * ns[cl], ns[cl], c->pts_perm, nullptr)) != BX_OK) return rc;
         }
-        { ProfScope ps(c, ds, 3); if ((rc = bxk_patch_features(c, ds, patches, kn, P, &st->des_r[i], aligned_z, c->R_sc[i][cl] + (size_t)k0 * 9, feat)) != BX_OK) return rc; }
+        { ProfScope ps(c, ds, 3); if ((rc = bxk_patch_features(c, ds, patches, kn, P, &st->des_r[i], aligned_z, c->R_sc[i][cl] + (size_t)k0 * 9, feat, pcnt, pcnt ? c->kpts[cl] + (size_t)k0 * 3 : nullptr)) != BX_OK) return rc; }
         if (capc) {
             if ((rc = cap_copy(ds, c->cap.pts_perm, c->pts_perm, (size_t)ns[cl] * 3)) != BX_OK) return rc;
             if ((rc = cap_copy(ds, c->cap.patches, patches, (size_t)K * P * 3)) != BX_OK) return rc;

@@ -117,6 +117,7 @@ struct bx_ctx {
     // carved buffers (see bx_api.hip)
     float *act0, *act1;                 // conv ping-pong
     float* patches;                     // [K][P][3]
+    int32_t *pcnt, *pcnt2;              // [K] real slots per patch (hit-count hand-over; pcnt2: the target chain's scratch in the latency form)
     int32_t* ball_idx;                  // [K][P] ball_query indices (the reference op's first output; kept for parity of the op)
     float* feat;                        // [K][3][140][16]
     float* pts_perm;                    // [max_points][3]
@@ -209,17 +210,17 @@ int bxk_gather_rows(hipStream_t s, const float* pts, const int32_t* idx, int n, 
 int bxk_radius_hist(bx_ctx* c, hipStream_t s, const float* pts, int n_pts, const float* kpts, int nk);
 int bxk_radius_bisect(bx_ctx* c, hipStream_t s, int64_t n_orig, int nk, double threshold, double* des_r_out);
 int bxk_ball_group(bx_ctx* c, hipStream_t s, const float* pts_perm, int n, const float* kpts, int K, const double* radius,
-                   int P, int32_t* idx_out, float* patches_out);
+                   int P, int32_t* idx_out, float* patches_out, int32_t* cnt_out = nullptr);
 int bxk_ball_prepare(bx_ctx* c, hipStream_t s, const float* const* clouds, const int* ns, const int32_t* const* perms,
                      const float* const* kpts, int nclouds, int K, const double* radius, int S, const double* pw_hint);
 int bxk_ball_grids(bx_ctx* c, hipStream_t s, const float* const* clouds, const int* ns, const int32_t* const* perms, int nclouds,
                    const double* radius, int S, const double* pw_hint, int i0 = 0, int ni = -1);      // scales [i0, i0 + ni) (ni < 0: to S); honours c->skip
 int bxk_ball_rows(bx_ctx* c, hipStream_t s, const float* const* kpts, int nclouds, int S, int k0, int K, int i0 = 0, int ni = -1);
 int bxk_ball_query(bx_ctx* c, hipStream_t s, int set, int n, const float* kpts, int k0, int K, const double* radius, int P,
-                   int32_t* idx_out, float* patches_out);
+                   int32_t* idx_out, float* patches_out, int32_t* cnt_out = nullptr);   // cnt_out: hit-count hand-over (only the real slots are written)
 int bxk_radius_bisect_all(bx_ctx* c, hipStream_t s, int64_t n_orig, int nk, const double* thresholds_host, int nthr, double* des_r_out);
 int bxk_patch_features(bx_ctx* c, hipStream_t s, const float* patches, int K, int P, const double* radius, int aligned,
-                       float* R_out, float* feat_out);
+                       float* R_out, float* feat_out, const int32_t* cnt = nullptr, const float* kpts = nullptr);   // cnt + kpts: counted patches (hit-count hand-over)
 int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, const int32_t* units_dev, int max_units,
              float* out);
 int bxk_wino43_weights(const float* w, int nchunk, int fold, int cout, float** d_out);

@@ -425,8 +425,8 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
                                                         const int32_t* __restrict__ pnum, int logpw, const float4* __restrict__ pts4,
                                                         const float* __restrict__ kpts, int K,
                                                         const double* __restrict__ radius, int P, int32_t* __restrict__ idx_out,
-                                                        float* __restrict__ patches, const int32_t* __restrict__ skip,
-                                                        long long* __restrict__ dbg)
+                                                        float* __restrict__ patches, int32_t* __restrict__ cnt_out,
+                                                        const int32_t* __restrict__ skip, long long* __restrict__ dbg)
 {
     if (skip && *skip) return;
     constexpr int QT = 64 * QW;
@@ -595,8 +595,15 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
     const int first = nhit > 0 ? list[0] : 0;
     F3* out3 = reinterpret_cast<F3*>(patches) + (size_t)q * P;
     int32_t* outi = idx_out ? idx_out + (size_t)q * P : nullptr;
+    // Hit-count hand-over (cnt_out != nullptr, the whole-pair path): slots [nreal, P) of a patch are copies of the keypoint -- the padded
+    // slots (group_idx == group_idx[0]) and slot P - 1 (models/patch_embedder.py:105-111) -- so only the REAL slots are written, with
+    // nreal = clamp(hits, 1, P - 1): slot 0 is always a cloud point (the first hit, or point 0 of the permuted cloud when the ball is
+    // empty: the reference's quirk), slot P - 1 never is.  patch_axis_kernel / patch_features_kernel take the count and treat the rest
+    // analytically (k_patch.hip); a 0.5 % patch is ~83 % copies of the keypoint that are neither gathered, written nor read back.
+    const int nout = cnt_out ? (nhit < 1 ? 1 : (nhit < P - 1 ? nhit : P - 1)) : P;
+    if (cnt_out && tid == 0) cnt_out[q] = nout;
     constexpr int OU = QW >= 4 ? 4 : 8;     // P = 1024: one pass, every gather of the keypoint in flight at once
-    for (int j0 = 0; j0 < P; j0 += QT * OU) {
+    for (int j0 = 0; j0 < nout; j0 += QT * OU) {
         int idx[OU];
         float4 p[OU];
 #pragma unroll
@@ -609,7 +616,7 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
 #pragma unroll
         for (int u = 0; u < OU; ++u) {
             const int j = j0 + u * QT + tid;
-            if (j < P) {
+            if (j < nout) {
                 float mask = (idx[u] == first) ? 1.0f : 0.0f;
                 if (j == 0) mask = 0.0f;
                 if (j == P - 1) mask = 1.0f;
@@ -628,7 +635,7 @@ __global__ __launch_bounds__(64 * QW, 8) void ball_query_kernel(const float4* __
 }
 
 template <int LOGC, int QW>
-int launch_query_w(bx_ctx* c, hipStream_t s, int set, int k0, int K, const float* kpts, const double* radius, int P, int32_t* idx_out, float* patches_out)
+int launch_query_w(bx_ctx* c, hipStream_t s, int set, int k0, int K, const float* kpts, const double* radius, int P, int32_t* idx_out, float* patches_out, int32_t* cnt_out)
 {
     const size_t lds = ((size_t)64 << LOGC) * (LOGC >= BX_BALL_NOPRE_LOGC ? 8 : 12) + (((size_t)P * 4 + 7) & ~(size_t)7) + (size_t)NPMAX * 8;   // bitmap | per-word prefix | ordered index list | pieces
     if (lds > 160 * 1024) { bx_set_error("bxk_ball_group: P=%d needs %zu B of LDS per keypoint (> 160 KiB)", P, lds); return BX_ERR_ARG; }
@@ -640,13 +647,13 @@ int launch_query_w(bx_ctx* c, hipStream_t s, int set, int k0, int K, const float
     hipLaunchKernelGGL((ball_query_kernel<LOGC, QW>), dim3(K), dim3(64 * QW), lds, s, c->ball_sorted + j * c->ball_st_pts,
                        c->ball_start + j * c->ball_st_cnt, c->ball_grid + j, c->ball_ptab + j * c->ball_st_tab + (size_t)k0 * NPMAX,
                        c->ball_pnum + j * c->ball_st_num + k0, c->ball_logpw[set], c->ball_pts4 + j * c->ball_st_pts, kpts, K,
-                       radius, P, idx_out, patches_out, c->skip, getenv("BX_BALL_DEBUG") ? c->ball_dbg : nullptr);
+                       radius, P, idx_out, patches_out, cnt_out, c->skip, getenv("BX_BALL_DEBUG") ? c->ball_dbg : nullptr);
     BX_LAUNCH_CHECK();
     return BX_OK;
 }
 
 template <int LOGC>
-int launch_query(bx_ctx* c, hipStream_t s, int set, int k0, int K, const float* kpts, const double* radius, int P, int32_t* idx_out, float* patches_out)
+int launch_query(bx_ctx* c, hipStream_t s, int set, int k0, int K, const float* kpts, const double* radius, int P, int32_t* idx_out, float* patches_out, int32_t* cnt_out)
 {
     // waves per keypoint: 4 for the large neighbourhoods (their candidate scan dominates), 1 for the small ones (the
     // per-keypoint chain of dependent memory round trips dominates and more independent workgroups hide it better)
@@ -655,9 +662,9 @@ int launch_query(bx_ctx* c, hipStream_t s, int set, int k0, int K, const float* 
     // measured (K = 5000, P = 1024): 4 waves win whenever the bitmap sweep is long (n > 32768: LOGC >= 4) or the neighbourhood is
     // large (hint from the radius threshold); 2 waves only for small neighbourhoods in small clouds
     const int w = forced ? forced : (LOGC >= 4 ? 4 : c->ball_waves_hint);
-    if (w >= 4) return launch_query_w<LOGC, 4>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out);
-    if (w == 1) return launch_query_w<LOGC, 1>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out);
-    return launch_query_w<LOGC, 2>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out);
+    if (w >= 4) return launch_query_w<LOGC, 4>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out, cnt_out);
+    if (w == 1) return launch_query_w<LOGC, 1>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out, cnt_out);
+    return launch_query_w<LOGC, 2>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out, cnt_out);
 }
 }  // namespace
 
@@ -778,8 +785,9 @@ int bxk_ball_prepare(bx_ctx* c, hipStream_t s, const float* const* clouds, const
 
 // The query of one prepared set: n = size of its cloud, radius = device pointer to the radius of its scale.
 // Keypoints [k0, k0 + K) of the set (kpts = the whole keypoint array); rows of idx_out / patches_out are relative to k0.
+// cnt_out (nullable, int32 [K] relative to k0): hit-count hand-over -- only the real slots of a patch are written + their number.
 int bxk_ball_query(bx_ctx* c, hipStream_t s, int set, int n, const float* kpts, int k0, int K, const double* radius, int P,
-                   int32_t* idx_out, float* patches_out)
+                   int32_t* idx_out, float* patches_out, int32_t* cnt_out)
 {
     if (K <= 0) return BX_OK;
     kpts += (size_t)k0 * 3;
@@ -787,12 +795,12 @@ int bxk_ball_query(bx_ctx* c, hipStream_t s, int set, int n, const float* kpts, 
     bx_prof_mark(c, s, 12, 1);
     int rc = BX_OK;
     switch (ball_logc(n)) {
-    case 3: rc = launch_query<3>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out); break;
-    case 4: rc = launch_query<4>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out); break;
-    case 5: rc = launch_query<5>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out); break;
-    case 6: rc = launch_query<6>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out); break;
-    case 7: rc = launch_query<7>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out); break;
-    default: rc = launch_query<8>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out); break;
+    case 3: rc = launch_query<3>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out, cnt_out); break;
+    case 4: rc = launch_query<4>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out, cnt_out); break;
+    case 5: rc = launch_query<5>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out, cnt_out); break;
+    case 6: rc = launch_query<6>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out, cnt_out); break;
+    case 7: rc = launch_query<7>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out, cnt_out); break;
+    default: rc = launch_query<8>(c, s, set, k0, K, kpts, radius, P, idx_out, patches_out, cnt_out); break;
     }
     bx_prof_mark(c, s, 12, 0);
     return rc;
@@ -800,7 +808,7 @@ int bxk_ball_query(bx_ctx* c, hipStream_t s, int set, int n, const float* kpts, 
 
 // stage entry point (bx_ball_group): one already permuted cloud, one radius
 int bxk_ball_group(bx_ctx* c, hipStream_t s, const float* pts_perm, int n, const float* kpts, int K, const double* radius,
-                   int P, int32_t* idx_out, float* patches_out)
+                   int P, int32_t* idx_out, float* patches_out, int32_t* cnt_out)
 {
     if (K <= 0) return BX_OK;
     if (n <= 0 || P < 2) { bx_set_error("bxk_ball_group: n=%d P=%d", n, P); return BX_ERR_ARG; }
@@ -809,5 +817,5 @@ int bxk_ball_group(bx_ctx* c, hipStream_t s, const float* pts_perm, int n, const
     const int ns[1] = {n};
     int rc = bxk_ball_prepare(c, s, cl, ns, nullptr, kp, 1, K, radius, 1, nullptr);
     if (rc != BX_OK) return rc;
-    return bxk_ball_query(c, s, 0, n, kpts, 0, K, radius, P, idx_out, patches_out);
+    return bxk_ball_query(c, s, 0, n, kpts, 0, K, radius, P, idx_out, patches_out, cnt_out);
 }

@@ -27,17 +27,24 @@ constexpr int MAX_NS = 16;
 constexpr int NROWS = BX_RAD * BX_ELE;                 // 21 (shell, elevation) rows of BX_AZI voxels
 constexpr int RPW = (NROWS + PF_WAVES - 1) / PF_WAVES;   // candidate-list rows built per wave (3)
 
+// Counted patches (cnt != nullptr: the hit-count hand-over of ball_query_kernel, k_ball.hip): slots [cnt[q], P) are copies of the
+// keypoint kpts[q] that were never written.  Their offset from the centre (= slot P - 1 = the keypoint) is exactly +0, and a lane's
+// covariance partial fmaf(0, 0, c) == c for every c this chain can hold (it starts at +0 and (+0) + (-0) = +0: never -0), so the
+// lane-strided sums over the first cnt[q] slots are the sums over all P slots bit for bit.
 __global__ __launch_bounds__(256) void patch_axis_kernel(const float* __restrict__ patches, int K, int P, float* __restrict__ R_out,
-                                                         const int32_t* __restrict__ skip)
+                                                         const int32_t* __restrict__ skip, const int32_t* __restrict__ cnt,
+                                                         const float* __restrict__ kpts)
 {
     if (skip && *skip) return;
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= K) return;
     const float* pp = patches + (size_t)q * P * 3;
-    const float cx = pp[(size_t)(P - 1) * 3], cy = pp[(size_t)(P - 1) * 3 + 1], cz = pp[(size_t)(P - 1) * 3 + 2];
+    const float* cp = cnt ? kpts + (size_t)q * 3 : pp + (size_t)(P - 1) * 3;
+    const float cx = cp[0], cy = cp[1], cz = cp[2];
+    const int Pe = cnt ? cnt[q] : P;
     float c00 = 0.f, c01 = 0.f, c02 = 0.f, c11 = 0.f, c12 = 0.f, c22 = 0.f;
-    for (int i = lane; i < P; i += 64) {
+    for (int i = lane; i < Pe; i += 64) {
         const float dx = pp[(size_t)i * 3] - cx, dy = pp[(size_t)i * 3 + 1] - cy, dz = pp[(size_t)i * 3 + 2] - cz;
         c00 = fmaf(dx, dx, c00); c01 = fmaf(dx, dy, c01); c02 = fmaf(dx, dz, c02);
         c11 = fmaf(dy, dy, c11); c12 = fmaf(dy, dz, c12); c22 = fmaf(dz, dz, c22);
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(PF_THREADS) void patch_features_kernel(
     const float* __restrict__ patches, int K, int P, const double* __restrict__ radius, int aligned,
     const float* __restrict__ centres, const float* __restrict__ rowc, const float* __restrict__ rot, int nsample, float voxel_r,
     const float* __restrict__ pnt_w, const float* __restrict__ pnt_b, float* __restrict__ R_out, float* __restrict__ feat,
-    const int32_t* __restrict__ skip, int cap, long long* __restrict__ dbg)
+    const int32_t* __restrict__ skip, int cap, long long* __restrict__ dbg, const int32_t* __restrict__ cnt, const float* __restrict__ kpts)
 {
     if (skip && *skip) return;
     // optional cycle stamps (BX_BALL_DEBUG): {t0, normalised, row lists, query of wave 0, conv+store of wave 0}
@@ -114,7 +121,16 @@ __global__ __launch_bounds__(PF_THREADS) void patch_features_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* pp = patches + (size_t)q * P * 3;
     const float des_r = (float)(*radius);
-    const float cx = pp[(size_t)(P - 1) * 3], cy = pp[(size_t)(P - 1) * 3 + 1], cz = pp[(size_t)(P - 1) * 3 + 2];
+    // Counted patches (cnt != nullptr): only the first Pe = cnt[q] slots hold cloud points; the others are copies of the keypoint,
+    // i.e. the ZERO vector after centring (whatever the rotation).  They are dropped: (1) such a point lies within the voxel radius of
+    // the inner-shell centres only, behind every real point in patch order, so it can only take sample slots that the real hits
+    // leave empty; (2) in such a slot it contributes conv(0, 0, 0) = the bias -- exactly what the masked padding sample of an empty
+    // slot contributes (utils/common.py:440-447: padded slots are zeroed) -- and ReLU + max do not see the sign of a zero.  The
+    // features are bit-identical to those of the padded patch (tests/test_gpu_counted.py), the row lists hold real points only
+    // (no more overflowing inner-shell lists at the small scales) and the sweep below runs over Pe instead of P points.
+    const int Pe = cnt ? __builtin_amdgcn_readfirstlane(cnt[q]) : P;
+    const float* cp = cnt ? kpts + (size_t)q * 3 : pp + (size_t)(P - 1) * 3;
+    const float cx = cp[0], cy = cp[1], cz = cp[2];
     float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
     if (!aligned) {
 #pragma unroll
@@ -124,7 +140,7 @@ __global__ __launch_bounds__(PF_THREADS) void patch_features_kernel(
     }
 
     // ---- centre on the keypoint, rotate (delta @ R), normalise by the scale radius
-    for (int i = tid; i < P; i += PF_THREADS) {
+    for (int i = tid; i < Pe; i += PF_THREADS) {
         const float x = pp[(size_t)i * 3] - cx, y = pp[(size_t)i * 3 + 1] - cy, z = pp[(size_t)i * 3 + 2] - cz;
         float nx = x, ny = y, nzc = z;
         if (!aligned) {
@@ -160,10 +176,10 @@ __global__ __launch_bounds__(PF_THREADS) void patch_features_kernel(
             zc[r] = row < NROWS ? rowc[row * 2 + 1] : 0.f;
             base[r] = 0;
         }
-        for (int k0 = 0; k0 < P; k0 += 64) {
+        for (int k0 = 0; k0 < Pe; k0 += 64) {
             const int k = k0 + lane;
             float4 d = make_float4(0.f, 0.f, 1.0e30f, 0.f);
-            if (k < P) d = sp[k];
+            if (k < Pe) d = sp[k];
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 const int row = wave + r * PF_WAVES;
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(PF_THREADS) void patch_features_kernel(
         if (act) { qx = centres[v * 3]; qy = centres[v * 3 + 1]; qz = centres[v * 3 + 2]; }
         const int rl_len = rlen[row];
         const bool full = rl_len < 0;
-        const int len = act ? (full ? P : rl_len) : 0;
+        const int len = act ? (full ? Pe : rl_len) : 0;
         const unsigned short* rl = rlist + (size_t)row * cap;
         int cnt = 0;
         // the hits of a step in list order, up to nsample, as POSITIONS in the row's list (the point index itself for a row scanned over
@@ -262,7 +278,7 @@ __global__ __launch_bounds__(PF_THREADS) void patch_features_kernel(
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     int k = full ? i0 + j : ks[j];
-                    k = k < P ? k : P - 1;
+                    k = k < Pe ? k : Pe - 1;
                     const float4 d = sp[k];
                     const float dx = qx - d.x, dy = qy - d.y, dz = qz - d.z;
                     const float dd = (dx * dx + dy * dy) + dz * dz;
@@ -310,8 +326,9 @@ __global__ __launch_bounds__(PF_THREADS) void patch_features_kernel(
 }  // namespace
 
 int bxk_patch_features(bx_ctx* c, hipStream_t s, const float* patches, int K, int P, const double* radius, int aligned,
-                       float* R_out, float* feat_out)
+                       float* R_out, float* feat_out, const int32_t* cnt, const float* kpts)
 {
+    if (cnt && !kpts) { bx_set_error("bxk_patch_features: counted patches need the keypoints"); return BX_ERR_ARG; }
     if (K <= 0) return BX_OK;
     const int ns = c->p.voxel_sample;
     if (ns < 1 || ns > MAX_NS || P < 2 || P > 8192) { bx_set_error("bxk_patch_features: voxel_sample=%d P=%d unsupported", ns, P); return BX_ERR_ARG; }
@@ -323,10 +340,10 @@ int bxk_patch_features(bx_ctx* c, hipStream_t s, const float* patches, int K, in
         c->patch_attr_set = 1;
     }
     const float voxel_r = (float)(c->p.delta / (double)c->p.rad_n);
-    if (!aligned) hipLaunchKernelGGL(patch_axis_kernel, dim3((K + 3) / 4), dim3(256), 0, s, patches, K, P, R_out, c->skip);
+    if (!aligned) hipLaunchKernelGGL(patch_axis_kernel, dim3((K + 3) / 4), dim3(256), 0, s, patches, K, P, R_out, c->skip, cnt, kpts);
     hipLaunchKernelGGL(patch_features_kernel, dim3(K), dim3(PF_THREADS), lds, s, patches, K, P, radius, aligned, c->d_centres,
                        c->d_rowc, c->d_rot, ns, voxel_r, c->d_pnt_w, c->d_pnt_b, R_out, feat_out, c->skip, cap,
-                       getenv("BX_BALL_DEBUG") ? c->ball_dbg : nullptr);
+                       getenv("BX_BALL_DEBUG") ? c->ball_dbg : nullptr, cnt, kpts);
     BX_LAUNCH_CHECK();
     return BX_OK;
 }

@@ -55,7 +55,8 @@ class BxCapture(C.Structure):
 EXPORTS = ["bx_create", "bx_destroy", "bx_last_error", "bx_load_weights", "bx_workspace_bytes", "bx_register_pair",
            "bx_set_capture", "bx_keypoint_tile_bounds",
            "bx_profile_enable", "bx_profile_read", "bx_debug_read",
-           "bx_fps", "bx_radius", "bx_permute", "bx_ball_group", "bx_patch_features", "bx_desc_net", "bx_conv_layer",
+           "bx_fps", "bx_radius", "bx_permute", "bx_ball_group", "bx_patch_features", "bx_ball_group_counted", "bx_patch_features_counted",
+           "bx_desc_net", "bx_conv_layer",
            "bx_mutual", "bx_pose_net", "bx_hypotheses", "bx_consensus", "bx_ransac", "bx_kiss_solve", "bx_refine",
            "bx_pre_reserve", "bx_pre_voxel_downsample", "bx_pre_pca", "bx_random_perm",
            "bx_lane_create", "bx_lane_destroy", "bx_attach_lane",
@@ -303,6 +304,33 @@ class Context:
                                     C.c_int32(K), self._p(radius_dev), C.c_int32(P), self._p(idx), self._p(patches)),
              "bx_ball_group")
         return idx, patches
+
+    def ball_group_counted(self, pts_perm, kpts, radius_dev, P, fill=None):
+        """the counted form (bx_ball_group_counted): -> (patches [K, P, 3] of which only the first counts[k] slots of row k are
+        written -- the rest keeps `fill` (NaN by default, so that a consumer that reads beyond the count is caught) --, counts int32 [K])"""
+        t = self.torch
+        pts_perm, kpts = self._dev(pts_perm, t.float32), self._dev(kpts, t.float32)
+        radius_dev = self._dev(radius_dev, t.float64).reshape(-1)
+        K = kpts.shape[0]
+        patches = t.full((K, P, 3), float("nan") if fill is None else fill, dtype=t.float32, device=f"cuda:{self.device}")
+        counts = self._empty((K,), t.int32)
+        _chk(self.lib.bx_ball_group_counted(self.handle, self._stream(), self._p(pts_perm), C.c_int32(pts_perm.shape[0]), self._p(kpts),
+                                            C.c_int32(K), self._p(radius_dev), C.c_int32(P), self._p(patches), self._p(counts)),
+             "bx_ball_group_counted")
+        return patches, counts
+
+    def patch_features_counted(self, patches, counts, kpts, radius_dev, aligned):
+        t = self.torch
+        patches, kpts = self._dev(patches, t.float32), self._dev(kpts, t.float32)
+        counts = self._dev(counts, t.int32)
+        radius_dev = self._dev(radius_dev, t.float64).reshape(-1)
+        K, P, _ = patches.shape
+        R = self._empty((K, 9), t.float32)
+        feat = self._empty((K, 3, 140, 16), t.float32)
+        _chk(self.lib.bx_patch_features_counted(self.handle, self._stream(), self._p(patches), self._p(counts), self._p(kpts), C.c_int32(K),
+                                                C.c_int32(P), self._p(radius_dev), C.c_int32(int(aligned)), self._p(R), self._p(feat)),
+             "bx_patch_features_counted")
+        return R, feat
 
     # ---------------------------------------------------------------- pre-processing (SURVEY §8f rank 1)
     def pre_reserve(self, max_points):

@@ -211,6 +211,16 @@ int bx_permute(bx_ctx *ctx, void *stream, const float *pts, const int32_t *perm,
 int bx_ball_group(bx_ctx *ctx, void *stream, const float *pts_perm, int32_t n, const float *kpts, int32_t K,
                   const double *radius, int32_t P, int32_t *idx_out, float *patches_out);
 
+/* The COUNTED form of the two stages above (round 5; what bx_register_pair runs internally): slots [count, P) of a patch are
+ * copies of the keypoint -- the padded slots (group_idx == group_idx[:, :, 0]) and slot P - 1 of models/patch_embedder.py:105-111
+ * -- so bx_ball_group_counted writes only the first count_out[k] = clamp(hits, 1, P - 1) slots of patches_out [K][P][3] (the rest
+ * of a row is left untouched) and bx_patch_features_counted takes (patches, counts, kpts) and produces R_out / feat_out
+ * bit-identical to bx_patch_features on the padded patch (tests/test_gpu_counted.py).                                          */
+int bx_ball_group_counted(bx_ctx *ctx, void *stream, const float *pts_perm, int32_t n, const float *kpts, int32_t K,
+                          const double *radius, int32_t P, float *patches_out, int32_t *count_out);
+int bx_patch_features_counted(bx_ctx *ctx, void *stream, const float *patches, const int32_t *counts, const float *kpts,
+                              int32_t K, int32_t P, const double *radius, int32_t aligned_z, float *R_out, float *feat_out);
+
 /* axis_align + normalize + SPT + pnt_layer + max-pool (models/patch_embedder.py:122-170, 26-30, 73-77;
  * utils/common.py:431-498, 501-525, 709-726).  R_out float32 [K][9]; feat_out chunked [K][rad_n][ele*azi][16]. */
 int bx_patch_features(bx_ctx *ctx, void *stream, const float *patches, int32_t K, int32_t P, const double *radius,
