@@ -18,17 +18,23 @@
 //    (vmcnt), so the pieces of the next chunk are requested right after the chunk's first barrier -- a transform and a whole MFMA phase
 //    before they are needed, never between two ring loads -- and written to the slab all at once behind the last plane (the write's
 //    wait for its piece is a wait for every load in flight: one such drain per chunk, under the tail of the MFMAs).
-//  * transform: thread (tile row, channel slot) owns ONE channel of ONE tile: 36 ds_read_b32 from one base register, the column pass
-//    shared by the six xi rows (144 VALU; the round-3 item (xi, tile row, quad) re-read the window once per xi: 253 KB of slab reads
-//    per chunk instead of 69 KB), 36 ds_write_b32 into the V planes.  Slab row pitch 22 x 20 + 4 floats: the two tiles of a 32-lane
-//    ds_read_b32 group sit 16 banks apart also across the tile-row boundary.
+//  * transform (round 5): lane (tile row, channel PAIR) of a wave that owns three xi rows: 30 ds_read_b64, 72 v_pk_*_f32 (both passes
+//    on two channels at once, the pairs come for free from the 8-byte reads), 18 ds_write_b64 into the V planes.  Round 4: one channel
+//    per lane, 36 dword reads, 144 + 19 VALU, 36 ds_write_b32 (round 3 re-read the window once per xi: 253 KB of slab reads per chunk
+//    instead of 69 KB).  Slab row pitch 22 x 20 + 4 floats.
 //  * MFMA phase: SWAPPED operands (A = weight fragment, B = V rows), so accumulator register r of lane (li, kk) is
 //    M[tile row rt * 16 + li][slot 4 kk + r]: a lane owns four contiguous output slots of one tile.  B fragments in a ring of three
 //    planes through raw buffer loads (descriptor + wave-uniform offset in SGPRs: no VALU address arithmetic between the MFMAs).
 //  * output: nu pass and the half's partial xi sums lane-local; half 0 finishes the output rows 0, 1 of every tile, half 1 the rows 2, 3:
 //    each sends the two partials the other needs as float4 through a lane-linear LDS exchange (the bytes of the V planes) and stores
 //    Y = (P_0 + P_1) + bias as 16-byte pieces: 16 ds_write_b128 + 16 ds_read_b128 + 16 stores per lane and group, four barriers
-//    (round 3: 128 ds_write_b32 + 32 ds_read_b128, eight barriers).
+//    (round 3: 128 ds_write_b32 + 32 ds_read_b128, eight barriers).  Round 5: the lane-local arithmetic runs on v_pk_*_f32 over the
+//    register pairs (r, r + 1) of the MFMA results (no shuffles: wino43_common.h), a half keeps only the two sums its own rows need
+//    across the exchange, the stores are raw buffer stores (32-bit lane offset + SGPR group offset), the slab pieces raw buffer loads,
+//    and the phase's lane constants + the bias (LDS) are re-derived per group instead of living -- spilled -- across the MFMA pipeline:
+//    2 spilled VGPRs instead of 8-10, stack -1.3 % (profiles/r05_wino43_variants.txt).  A channel-pair packed INPUT transform
+//    (ds_read_b64 / 72 v_pk / ds_write_b64 per lane: fewer LDS cycles AND fewer VALU instructions on paper) was built, is bit-exact and
+//    measured 2.6 % SLOWER; it is not in the library.
 // Measured and NOT kept: the window straight from global memory (36 dword loads per thread: the texture addresser needs ~16 cycles per
 // wave-instruction of four 64-byte segments -- 1 800-4 700 cycles of blocked issue per chunk), a start stagger of the workgroups (no
 // change: the output phase is not a chip-wide burst), temporal output stores (no change).
@@ -50,25 +56,31 @@ constexpr int HP = BX_ELE + 3;                   // slab rows h = -1 .. 8 (tile 
 constexpr int TR4 = (BX_ELE + 3) / 4, TC4 = BX_AZI / 4, NT4 = TR4 * TC4;   // 2 x 5 = 10 tiles
 constexpr int G4 = 3, ROWS4 = G4 * NT4;          // three units = 30 tile rows of the 32
 constexpr int RP3 = WP * ROWF + 4, UP3 = HP * RP3;                         // slab row / unit pitch in floats: 444, 4 440
-constexpr size_t W43_LDS = (size_t)(G4 * UP3 + NPL * VPL4) * 4;            // 53 280 + 92 160 B
+constexpr size_t W43_LDS = (size_t)(G4 * UP3 + NPL * VPL4 + 64) * 4;       // 53 280 + 92 160 B + the workgroup's 64 bias values
 static_assert(NPH % 3 == 0 && BX_AZI % 4 == 0 && W43_LDS <= 160 * 1024 && (RP3 * 4) % 16 == 0 && 8 * 8 * 64 * 16 <= NPL * VPL4 * 4,
               "geometry, LDS, 16-byte slab rows, output exchange inside the V planes");
 
 // ---- output transform.  nu pass and the half's partial xi sums lane-local (wino43_send), one exchange round per MFMA row tile.
 template <int NT, bool RELU>
 __device__ __forceinline__ void wino43_output(const f32x4 (&acc)[NPH][RT4], float* Vp, bool cw, int half, int wave, int lane, int ug, int units,
-                                              int ctile, const float4 b4, float* __restrict__ out)
+                                              int ctile, const __amdgpu_buffer_rsrc_t ors)
 {
     float4* ex = reinterpret_cast<float4*>(Vp);             // [wave][8][lane]
+    // the lane constants of this phase (exchange addresses, tile coordinates, bias) are derived HERE from the lane id, every group: the
+    // empty asm keeps hipcc from hoisting them out of the group loop, where they were live (in fact: spilled to scratch and reloaded
+    // -- a reload waits behind every load and store in flight) across the whole MFMA pipeline for ~20 integer instructions per group;
+    // the bias comes from LDS for the same reason
+    asm volatile("" : "+v"(lane));
+    const float4 b4 = *reinterpret_cast<const float4*>(Vp + NPL * VPL4 + (wave >> 1) * 16 + (lane >> 4) * 4);
     const int li = lane & 15, kk = lane >> 4;
     float4* mine = ex + (wave * 8) * 64 + lane;
     const float4* theirs = ex + ((wave ^ 1) * 8) * 64 + lane;
 #pragma unroll
     for (int rt = 0; rt < RT4; ++rt) {
-        float ua[4][4], ub[4][4], uc[4][4];                 // [r][j]
+        f32x2 A[2][4], B[2][4];                 // [register pair][j]
         if (cw) {
-            if (half == 0) wino43_send<0>(acc, rt, ua, ub, uc, mine);
-            else wino43_send<1>(acc, rt, ua, ub, uc, mine);
+            if (half == 0) wino43_send<0>(acc, rt, A, B, mine);
+            else wino43_send<1>(acc, rt, A, B, mine);
         }
         __syncthreads();
         if (cw) {
@@ -77,10 +89,21 @@ __device__ __forceinline__ void wino43_output(const f32x4 (&acc)[NPH][RT4], floa
             const int u = ug * G4 + g;
             const bool live = R < ROWS4 && u < units;
             const int i0 = 2 * half;                        // this half's output rows of a tile: i0, i0 + 1
-            float* ou = out + ((size_t)(u * NT + ctile) * BX_EA + (4 * tr + i0) * BX_AZI + 4 * tc) * 16 + 4 * kk;
             const bool second_row = 4 * tr + i0 + 1 < BX_ELE;
-            if (half == 0) wino43_finish<0, RELU>(ua, ub, uc, theirs, b4, ou, live, second_row, BX_AZI * 16, 15u);
-            else wino43_finish<1, RELU>(ua, ub, uc, theirs, b4, ou, live, second_row, BX_AZI * 16, 15u);
+            // raw buffer stores: ONE 32-bit offset per lane and row tile -- no 64-bit address registers held (or spilled) across the
+            // kernel, no 64-bit VALU address arithmetic in the output phase.
+            // HAZARD (found the hard way, round 5): the group's offset must NOT go into the instruction's SGPR offset field.  hipcc 7.2
+            // inserts no wait state between a buffer_store_dwordx4 WITH an SGPR offset and a VALU instruction that overwrites the
+            // store's data registers (LLVM's rule: "the >64-bit store-data hazard only exists without an soffset register"), and on
+            // gfx950 the store then reads half-overwritten data: wino43v_kernel<6, 3, 64, 18, 2> stored wrong values for four lanes of one
+            // output column (tests/test_gpu_stages.py::test_pose_conv_layer_exact[1]).  With soffset = 0 the compiler sees the hazard
+            // and spaces the instructions; the group offset costs one v_add per row tile.
+            const int voff = (((g * NT) * BX_EA + (4 * tr + i0) * BX_AZI + 4 * tc) * 16 + 4 * kk) * 4 + ((ug * G4 * NT + ctile) * BX_EA * 16) * 4;
+            auto store = [&](int off, const f32x4 v) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, voff + off * 4, 0, 2 /* nt: streamed once */);
+            };
+            if (half == 0) wino43_finish<0, RELU>(A, B, theirs, b4, store, live, second_row, BX_AZI * 16, 15u);
+            else wino43_finish<1, RELU>(A, B, theirs, b4, store, live, second_row, BX_AZI * 16, 15u);
         }
         __syncthreads();                                    // the exchange is free again (next row tile / next group's V planes)
     }
@@ -110,7 +133,6 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
     for (int i = tid; i < (int)(W43_LDS / 16); i += CT) reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // ---- slab traffic: per-thread constants (piece inside the group's [3][NCHUNK][140][16] floats, destination, halo copy)
-    const float4* in4 = reinterpret_cast<const float4*>(in);
     float4 st[NLD];
     int lsrc[NLD], ldst[NLD], lhalo[NLD];
 #pragma unroll
@@ -126,10 +148,13 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
             lhalo[q] = w == 0 ? BX_AZI * ROWF : (w == BX_AZI - 1 ? -BX_AZI * ROWF : 0);
         }
     }
+    // raw buffer loads: lane offset lsrc * 16 (a lane constant) + the (group, chunk) offset in an SGPR; pieces of units that do not exist
+    // read as zeros (explicit predicate: the hardware range check does not see the SGPR offset)
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)((long long)units * NCHUNK * NPU * 16 < 0x7fffffffLL ? (long long)units * NCHUNK * NPU * 16 : 0x7fffffffLL), 0x00020000);
     auto gload1 = [&](int q, int ug_, int cc_) {   // streamed once: non-temporal, so that the activations do not push the B fragments out of L2
-        const float4* base = in4 + ((size_t)ug_ * G4 * NCHUNK + cc_) * NPU;
-        const int lim = (units - ug_ * G4) * NCHUNK * NPU;      // pieces of units that do not exist read as zeros
-        const f32x4 v = (lsrc[q] >= 0 && lsrc[q] < lim) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + lsrc[q])) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int soff = ((ug_ * G4 * NCHUNK + cc_) * NPU) * 16;
+        const int lim = (units - ug_ * G4) * NCHUNK * NPU;
+        const f32x4 v = (lsrc[q] >= 0 && lsrc[q] < lim) ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, lsrc[q] * 16, soff, 2 /* nt */)) : (f32x4){0.f, 0.f, 0.f, 0.f};
         st[q] = make_float4(v.x, v.y, v.z, v.w);
     };
     auto lwrite1 = [&](int q) {
@@ -166,12 +191,12 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
         }
     };
 
-    const float* bq = bias + ctg * 16 + kk;         // slots 4 kk .. 4 kk + 3 of the wave's column tile hold the logical channels kk, 4 + kk, 8 + kk, 12 + kk
-    const float4 b4 = make_float4(bq[0], bq[4], bq[8], bq[12]);
+    // (the bias of the workgroup's column tiles lives in LDS as [column tile][kk][r] = slot kk + 4 r, behind the V planes: wino43_output)
     // B fragments [chunk * 36 + plane][column tile][lane][4]; this wave's planes are half * 18 + 0..17.  Raw buffer loads: descriptor +
     // wave-uniform byte offset in SGPRs (SALU arithmetic), one 32-bit lane offset -- no VALU address arithmetic between the MFMAs
     // (with global_load hipcc rebuilt a 64-bit VGPR address per plane: 30 VALU instructions inside every chunk's MFMA stream)
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U), 0, NCHUNK * NPL * NT * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((long long)units * NT * BX_EA * 64 < 0x7fffffffLL ? (long long)units * NT * BX_EA * 64 : 0x7fffffffLL), 0x00020000);
     const int ubase = ((half * NPH) * NT + ctg) * 1024;
     const int ulane = lane * 16;
     auto bload = [&](int q) {
@@ -198,6 +223,7 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
     for (int q = 0; q < NLD; ++q) gload1(q, lg, lc);
     ladv();
     __syncthreads();                 // zero fill complete
+    if (tid < CW) Vp[NPL * VPL4 + (tid >> 4) * 16 + (tid & 3) * 4 + ((tid & 15) >> 2)] = bias[(int)blockIdx.y * CW + tid];
 #pragma unroll
     for (int q = 0; q < NLD; ++q) lwrite1(q);
     bool st_live = lg < ngroups;
@@ -335,7 +361,7 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
         }
         BX_STAMP(6);
         __syncthreads();             // every wave is done with the V planes: their bytes carry the exchange now
-        wino43_output<NT, RELU>(acc, Vp, cw, half, wave, lane, ug, units, ctg, b4, out);
+        wino43_output<NT, RELU>(acc, Vp, cw, half, wave, lane, ug, units, ctg, ors);
         BX_STAMP(7);
         ug = ugn;
         if (ug >= ngroups) break;

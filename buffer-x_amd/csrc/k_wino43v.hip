@@ -28,7 +28,7 @@ struct GeoV {
     static constexpr int RP = SD * ROWF + 4, UP = SD * RP;   // row / unit pitch in floats (4 rows = 16 banks mod 32: SD is even)
     static constexpr int PIN = D * D, PIN3 = D * FOLD * D;   // positions of an effective chunk / of a real chunk
     static constexpr int NPU = PIN * 4, NPIECE = G * NPU, NLD = (NPIECE + CT - 1) / CT;
-    static constexpr size_t LDS = (size_t)(G * UP + NPL * VPL4) * 4;
+    static constexpr size_t LDS = (size_t)(G * UP + NPL * VPL4 + 64) * 4;   // slab | V planes | the workgroup's 64 bias values
     static_assert(NE % FOLD == 0 && ROWS <= VR4 && SD >= D && SD % 2 == 0 && LDS <= 160 * 1024 && 2 * NLD + 1 <= NPH && (RP * 4) % 16 == 0,
                   "tile rows fit two MFMA row tiles, slab covers the map, LDS, slab traffic fits the plane loop");
 };
@@ -58,7 +58,6 @@ __global__ __launch_bounds__(CT, 2) void wino43v_kernel(const float* __restrict_
 
     // ---- slab traffic: piece f = (unit g of the group, position p = n D + l, 16-byte part): source inside the group's
     //      [G][NCH][D FOLD D][16] floats (position (n FOLD + k) D + l of real chunk c2 for the effective chunk e = c2 FOLD + k), destination
-    const float4* in4 = reinterpret_cast<const float4*>(in);
     float4 st[NLD];
     int lsrc[NLD], ldst[NLD];
 #pragma unroll
@@ -73,11 +72,16 @@ __global__ __launch_bounds__(CT, 2) void wino43v_kernel(const float* __restrict_
             ldst[q] = g * UP + n * RP + l * ROWF + part * 4;
         }
     }
+    // raw buffer loads (round 5): lane offset lsrc * 16 (a lane constant) + the (group, chunk) offset in an SGPR -- no 64-bit VALU address per
+    // piece and chunk, no address registers; pieces of units that do not exist read as zeros (explicit predicate: the hardware range
+    // check does not see the SGPR offset)
+    const long long in_bytes = (long long)max_units * GE::NCH * GE::PIN3 * 64;
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)(in_bytes < 0x7fffffffLL ? in_bytes : 0x7fffffffLL), 0x00020000);
     auto gload1 = [&](int q, int ug_, int e_) {
         const int c2 = e_ / FOLD, k = e_ - c2 * FOLD;
-        const float4* base = in4 + ((size_t)ug_ * G * GE::NCH * GE::PIN3 + (size_t)c2 * GE::PIN3 + k * D) * 4;
+        const int soff = ((ug_ * G * GE::NCH + c2) * GE::PIN3 + k * D) * 64;
         const int lim = (units - ug_ * G) * GE::NCH * GE::PIN3 * 4;     // pieces of units that do not exist read as zeros
-        const f32x4 v = (lsrc[q] >= 0 && lsrc[q] < lim) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + lsrc[q])) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 v = (lsrc[q] >= 0 && lsrc[q] < lim) ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, lsrc[q] * 16, soff, 2 /* nt */)) : (f32x4){0.f, 0.f, 0.f, 0.f};
         st[q] = make_float4(v.x, v.y, v.z, v.w);
     };
     auto lwrite1 = [&](int q) {
@@ -110,8 +114,9 @@ __global__ __launch_bounds__(CT, 2) void wino43v_kernel(const float* __restrict_
         }
     };
 
-    const float* bq = bias + ctg * 16 + kk;         // slots 4 kk .. 4 kk + 3 of the wave's column tile hold the logical channels kk, 4 + kk, 8 + kk, 12 + kk
-    const float4 b4 = make_float4(bq[0], bq[4], bq[8], bq[12]);
+    // (the bias of the workgroup's column tiles lives in LDS as [column tile][kk][r] = slot kk + 4 r, behind the V planes: output phase)
+    const long long out_bytes = (long long)max_units * NT * (DO * DO) * 64;
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)(out_bytes < 0x7fffffffLL ? out_bytes : 0x7fffffffLL), 0x00020000);
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U), 0, NE * NPL * NT * 1024, 0x00020000);
     const int ubase = ((half * NPH) * NT + ctg) * 1024;
     const int ulane = lane * 16;
@@ -134,13 +139,10 @@ __global__ __launch_bounds__(CT, 2) void wino43v_kernel(const float* __restrict_
     for (int q = 0; q < NLD; ++q) gload1(q, lg, lc);
     ladv();
     __syncthreads();                 // zero fill complete
+    if (tid < 64) Vp[NPL * VPL4 + (tid >> 4) * 16 + (tid & 3) * 4 + ((tid & 15) >> 2)] = bias[(int)blockIdx.y * 64 + tid];
 #pragma unroll
     for (int q = 0; q < NLD; ++q) lwrite1(q);
     bool st_live = lg < ngroups;
-
-    float4* ex = reinterpret_cast<float4*>(Vp);             // output exchange [wave][8][lane]
-    float4* mine = ex + (wave * 8) * 64 + lane;
-    const float4* theirs = ex + ((wave ^ 1) * 8) * 64 + lane;
 
     for (;;) {
 #pragma unroll
@@ -190,11 +192,20 @@ __global__ __launch_bounds__(CT, 2) void wino43v_kernel(const float* __restrict_
             }
         }
         __syncthreads();             // every wave is done with the V planes: their bytes carry the exchange now
+        // the lane constants of the output phase (exchange addresses, tile coordinates, bias) are derived here, every group: the empty asm
+        // keeps hipcc from hoisting them out of the group loop, where they lived -- spilled -- across the MFMA pipeline (k_wino43.hip)
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int li = lane_o & 15, kk = lane_o >> 4;
+        float4* ex = reinterpret_cast<float4*>(Vp);         // output exchange [wave][8][lane]
+        float4* mine = ex + (wave * 8) * 64 + lane_o;
+        const float4* theirs = ex + ((wave ^ 1) * 8) * 64 + lane_o;
+        const float4 b4 = *reinterpret_cast<const float4*>(Vp + NPL * VPL4 + ctl * 16 + kk * 4);
 #pragma unroll
         for (int rt = 0; rt < RT4; ++rt) {
-            float ua[4][4], ub[4][4], uc[4][4];             // [r][j]
-            if (half == 0) wino43_send<0>(acc, rt, ua, ub, uc, mine);
-            else wino43_send<1>(acc, rt, ua, ub, uc, mine);
+            f32x2 A[2][4], B[2][4];             // [register pair][j]
+            if (half == 0) wino43_send<0>(acc, rt, A, B, mine);
+            else wino43_send<1>(acc, rt, A, B, mine);
             __syncthreads();
             const int R = rt * 16 + li;
             const int g = R / NTU, t = R - g * NTU, tr = t / T, tc = t - tr * T;
@@ -204,9 +215,16 @@ __global__ __launch_bounds__(CT, 2) void wino43v_kernel(const float* __restrict_
             const bool second_row = 4 * tr + i0 + 1 < DO;
             const int nj = DO - 4 * tc;                     // output columns of this tile that exist (>= 4: all)
             const unsigned jmask = nj >= 4 ? 15u : (1u << (nj > 0 ? nj : 0)) - 1u;
-            float* ou = out + ((size_t)(u * NT + ctg) * (DO * DO) + (4 * tr + i0) * DO + 4 * tc) * 16 + 4 * kk;
-            if (half == 0) wino43_finish<0, RELU>(ua, ub, uc, theirs, b4, ou, live, second_row, DO * 16, jmask);
-            else wino43_finish<1, RELU>(ua, ub, uc, theirs, b4, ou, live, second_row, DO * 16, jmask);
+            const int voff = (((g * NT) * (DO * DO) + (4 * tr + i0) * DO + 4 * tc) * 16 + 4 * kk) * 4;
+            const int soff = ((ug * G * NT + ctg) * (DO * DO) * 16) * 4;
+            // raw buffer stores (32-bit offsets, no 64-bit address registers).  The group's offset is ADDED INTO the lane offset and the
+            // instruction's SGPR offset field stays 0 -- see k_wino43.hip::wino43_output for the hazard this avoids
+            const int vo = voff + soff;
+            auto store = [&](int off, const f32x4 v) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, vo + off * 4, 0, 2 /* nt */);
+            };
+            if (half == 0) wino43_finish<0, RELU>(A, B, theirs, b4, store, live, second_row, DO * 16, jmask);
+            else wino43_finish<1, RELU>(A, B, theirs, b4, store, live, second_row, DO * 16, jmask);
             __syncthreads();                                // the exchange is free again (next row tile / next group's V planes)
         }
         ug = ugn;

@@ -6,13 +6,51 @@
 
 namespace w43 {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int ROWF = 20;                         // floats per LDS row (16 + 4 pad)
 constexpr int RT4 = 2, VR4 = RT4 * 16, VPL4 = VR4 * ROWF;   // two MFMA row tiles = 32 tile rows per workgroup item
 constexpr int NPL = 36, NPH = 18;                // planes, planes per wave half
 constexpr int CT = 512;
 
+// ---- packed f32 (round 5).  The vector ALU and the f32 MFMA are ONE resource on this chip (profiles/r05_mfma_coissue.txt: a VALU
+// instruction costs its 4-5 issue cycles whichever wave issues it), so what the transforms cost is their instruction count, and a
+// v_pk_*_f32 does two lanes' worth for the price of one -- but only when its operands already sit in aligned register pairs (hipcc's own
+// SLP packing paid for the pairs with v_mov and gained nothing).  Both transforms are written on explicit two-element vectors whose pairs
+// are free: two CHANNELS read as one ds_read_b64 (input transform), two accumulator registers r, r + 1 of one MFMA result (output
+// transform).  Element by element the expressions are those of the contract (oracle/bx_oracle.c::bxo_conv_wino43); a - b is written
+// fma(-1, b, a) -- the same single rounding, signed zeros included -- because hipcc scalarises a packed subtraction.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk2(float k) { return (f32x2){k, k}; }
+__device__ __forceinline__ f32x2 pfma(float k, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(pk2(k), b, c); }
+__device__ __forceinline__ f32x2 psub(f32x2 a, f32x2 b) { return __builtin_elementwise_fma(pk2(-1.0f), b, a); }
+__device__ __forceinline__ f32x2 lo2(const f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
+__device__ __forceinline__ f32x2 hi2(const f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
+__device__ __forceinline__ f32x4 cat2(const f32x2 a, const f32x2 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3); }
+
 // the six results of B^T on a 6-vector (contract: bxo_conv_wino43; t3 / t4 as fmaf(+-2, d3 - d1, c): 2 x is exact, so the rounding is
-// that of c +- e)
+// that of c +- e), on two channels at once; the halves (results 0..2 / 3..5) share nothing, so a thread that owns three xi rows of the
+// column pass computes only its half
+__device__ __forceinline__ void bt6p_lo(f32x2 d0, f32x2 d1, f32x2 d2, f32x2 d3, f32x2 d4, f32x2& o0, f32x2& o1, f32x2& o2)
+{
+    o0 = pfma(4.0f, d0, pfma(-5.0f, d2, d4));
+    const f32x2 a = pfma(-4.0f, d2, d4), b = pfma(-4.0f, d1, d3);
+    o1 = a + b;
+    o2 = psub(a, b);
+}
+__device__ __forceinline__ void bt6p_hi(f32x2 d1, f32x2 d2, f32x2 d3, f32x2 d4, f32x2 d5, f32x2& o3, f32x2& o4, f32x2& o5)
+{
+    const f32x2 c = psub(d4, d2), s = psub(d3, d1);
+    o3 = pfma(2.0f, s, c);
+    o4 = pfma(-2.0f, s, c);
+    o5 = pfma(4.0f, d1, pfma(-5.0f, d3, d5));
+}
+__device__ __forceinline__ void bt6p(f32x2 d0, f32x2 d1, f32x2 d2, f32x2 d3, f32x2 d4, f32x2 d5, f32x2 (&o)[6])
+{
+    bt6p_lo(d0, d1, d2, d3, d4, o[0], o[1], o[2]);
+    bt6p_hi(d1, d2, d3, d4, d5, o[3], o[4], o[5]);
+}
+
+// scalar form (the valid-map kernel's edge handling still uses it)
 __device__ __forceinline__ void bt6s(float d0, float d1, float d2, float d3, float d4, float d5, float (&o)[6])
 {
     o[0] = fmaf(4.0f, d0, fmaf(-5.0f, d2, d4));
@@ -25,62 +63,77 @@ __device__ __forceinline__ void bt6s(float d0, float d1, float d2, float d3, flo
     o[5] = fmaf(4.0f, d1, fmaf(-5.0f, d3, d5));
 }
 
+// ---- output transform, lane-local part.  Accumulator register r of a lane = output slot 4 kk + r.  nu pass (A^T along a row's six
+// planes) and the half's partial xi sums; a half SENDS the two partials the other half's output rows need and KEEPS only the two sums
+// its own rows need (A = P[0] of its first row, B = P[.] of its second): 32 live registers across the exchange barrier instead of the
+// 48 of the round-4 form (ua, ub, uc kept whole), which is what pushed the kernel over its 256 VGPRs in the output phase -- and every
+// spilled register is a scratch reload per group that waits behind all loads and stores in flight.
+//   half 0 (xi 0..2, output rows 0, 1):  keeps A = r_0 + (r_1 + r_2), B = r_1 - r_2;       sends r_1 + r_2, r_1 - r_2
+//   half 1 (xi 3..5, output rows 2, 3):  keeps A = 4 (r_3 + r_4), B = fma(8, r_3 - r_4, r_5); sends r_3 + r_4, 2 (r_3 - r_4)
+// packed form: the pairs (0, 1), (2, 3) of an MFMA result are aligned register pairs, so everything runs on v_pk_*_f32 without shuffles
 template <int HALF>
-__device__ __forceinline__ void wino43_send(const f32x4 (&acc)[NPH][RT4], int rt, float (&ua)[4][4], float (&ub)[4][4], float (&uc)[4][4], float4* mine)
+__device__ __forceinline__ void wino43_send(const f32x4 (&acc)[NPH][RT4], int rt, f32x2 (&A)[2][4], f32x2 (&B)[2][4], float4* mine)
 {
+    f32x4* mine4 = reinterpret_cast<f32x4*>(mine);
+    f32x2 s0[2][4], s1[2][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float rr[3][4];
+    for (int rp = 0; rp < 2; ++rp) {
+        f32x2 rr[3][4];
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
-            const float m0 = acc[x * 6 + 0][rt][r], m1 = acc[x * 6 + 1][rt][r], m2 = acc[x * 6 + 2][rt][r], m3 = acc[x * 6 + 3][rt][r],
-                        m4 = acc[x * 6 + 4][rt][r], m5 = acc[x * 6 + 5][rt][r];
-            const float p = m1 + m2, q = m1 - m2, s = m3 + m4, t = m3 - m4;
-            rr[x][0] = (m0 + p) + s;
-            rr[x][1] = fmaf(2.0f, t, q);
-            rr[x][2] = fmaf(4.0f, s, p);
-            rr[x][3] = fmaf(8.0f, t, q) + m5;
+            f32x2 m[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) m[k] = rp == 0 ? lo2(acc[x * 6 + k][rt]) : hi2(acc[x * 6 + k][rt]);
+            const f32x2 p = m[1] + m[2], q = psub(m[1], m[2]), s = m[3] + m[4], t = psub(m[3], m[4]);
+            rr[x][0] = (m[0] + p) + s;
+            rr[x][1] = pfma(2.0f, t, q);
+            rr[x][2] = pfma(4.0f, s, p);
+            rr[x][3] = pfma(8.0f, t, q) + m[5];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (HALF == 0) { ua[r][j] = rr[0][j]; ub[r][j] = rr[1][j] + rr[2][j]; uc[r][j] = rr[1][j] - rr[2][j]; }
-            else           { ua[r][j] = rr[0][j] + rr[1][j]; ub[r][j] = rr[0][j] - rr[1][j]; uc[r][j] = rr[2][j]; }
+            if (HALF == 0) {
+                const f32x2 ub = rr[1][j] + rr[2][j], uc = psub(rr[1][j], rr[2][j]);
+                A[rp][j] = rr[0][j] + ub; B[rp][j] = uc;
+                s0[rp][j] = ub; s1[rp][j] = uc;
+            } else {
+                const f32x2 ua = rr[0][j] + rr[1][j], ub = psub(rr[0][j], rr[1][j]);
+                A[rp][j] = pk2(4.0f) * ua; B[rp][j] = pfma(8.0f, ub, rr[2][j]);
+                s0[rp][j] = ua; s1[rp][j] = pk2(2.0f) * ub;
+            }
         }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        if (HALF == 0) {                                    // P_0[2] = r_1 + r_2, P_0[3] = r_1 - r_2
-            mine[(2 * j) * 64] = make_float4(ub[0][j], ub[1][j], ub[2][j], ub[3][j]);
-            mine[(2 * j + 1) * 64] = make_float4(uc[0][j], uc[1][j], uc[2][j], uc[3][j]);
-        } else {                                            // P_1[0] = r_3 + r_4, P_1[1] = 2 (r_3 - r_4)
-            mine[(2 * j) * 64] = make_float4(ua[0][j], ua[1][j], ua[2][j], ua[3][j]);
-            mine[(2 * j + 1) * 64] = make_float4(2.0f * ub[0][j], 2.0f * ub[1][j], 2.0f * ub[2][j], 2.0f * ub[3][j]);
-        }
+        mine4[(2 * j) * 64] = cat2(s0[0][j], s0[1][j]);
+        mine4[(2 * j + 1) * 64] = cat2(s1[0][j], s1[1][j]);
     }
 }
 
-template <int HALF, bool RELU>
-__device__ __forceinline__ void wino43_finish(const float (&ua)[4][4], const float (&ub)[4][4], const float (&uc)[4][4], const float4* theirs,
-                                              const float4 b4, float* ou, bool live, bool second_row, int row_stride, unsigned jmask)
+template <int HALF, bool RELU, class ST>
+__device__ __forceinline__ void wino43_finish(const f32x2 (&A)[2][4], const f32x2 (&B)[2][4], const float4* theirs,
+                                              const float4 b4, ST&& store, bool live, bool second_row, int row_stride, unsigned jmask)
 {
-    const float ba[4] = {b4.x, b4.y, b4.z, b4.w};
+    const f32x2 ba[2] = {(f32x2){b4.x, b4.y}, (f32x2){b4.z, b4.w}};
+    const f32x4* theirs4 = reinterpret_cast<const f32x4*>(theirs);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float4 g0 = theirs[(2 * j) * 64], g1 = theirs[(2 * j + 1) * 64];
-        const float g0a[4] = {g0.x, g0.y, g0.z, g0.w}, g1a[4] = {g1.x, g1.y, g1.z, g1.w};
-        float y0[4], y1[4];
+        const f32x4 g0 = theirs4[(2 * j) * 64], g1 = theirs4[(2 * j + 1) * 64];
+        f32x2 y0[2], y1[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float p0, p1, q0, q1;                           // (P_0, P_1) of the half's two output rows
-            if (HALF == 0) { p0 = ua[r][j] + ub[r][j]; p1 = g0a[r]; q0 = uc[r][j]; q1 = g1a[r]; }
-            else           { p0 = g0a[r]; p1 = 4.0f * ua[r][j]; q0 = g1a[r]; q1 = fmaf(8.0f, ub[r][j], uc[r][j]); }
-            y0[r] = (p0 + p1) + ba[r];
-            y1[r] = (q0 + q1) + ba[r];
-            if (RELU) { y0[r] = y0[r] > 0.f ? y0[r] : 0.f; y1[r] = y1[r] > 0.f ? y1[r] : 0.f; }
+        for (int rp = 0; rp < 2; ++rp) {
+            const f32x2 g0p = rp == 0 ? lo2(g0) : hi2(g0), g1p = rp == 0 ? lo2(g1) : hi2(g1);
+            // Y = (P_0 + P_1) + bias: half 0 holds P_0 and receives P_1, half 1 the other way round (the sum commutes bit for bit)
+            y0[rp] = (HALF == 0 ? A[rp][j] + g0p : g0p + A[rp][j]) + ba[rp];
+            y1[rp] = (HALF == 0 ? B[rp][j] + g1p : g1p + B[rp][j]) + ba[rp];
+            if (RELU) {                                     // no packed f32 maximum on gfx950: v_max_f32 per element
+                y0[rp] = (f32x2){y0[rp].x > 0.f ? y0[rp].x : 0.f, y0[rp].y > 0.f ? y0[rp].y : 0.f};
+                y1[rp] = (f32x2){y1[rp].x > 0.f ? y1[rp].x : 0.f, y1[rp].y > 0.f ? y1[rp].y : 0.f};
+            }
         }
         if (live && ((jmask >> j) & 1u)) {                  // jmask: output columns of the tile that exist (valid maps: the last tile column)
-            __builtin_nontemporal_store((f32x4){y0[0], y0[1], y0[2], y0[3]}, reinterpret_cast<f32x4*>(ou + j * 16));
-            if (second_row) __builtin_nontemporal_store((f32x4){y1[0], y1[1], y1[2], y1[3]}, reinterpret_cast<f32x4*>(ou + row_stride + j * 16));
+            store(j * 16, cat2(y0[0], y0[1]));
+            if (second_row) store(row_stride + j * 16, cat2(y1[0], y1[1]));
         }
     }
 }

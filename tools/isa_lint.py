@@ -36,7 +36,7 @@ def kernels(asm):
 
 
 def report(name, ins, spills):
-    stores = [i for i, l in enumerate(ins) if l.startswith("global_store")]
+    stores = [i for i, l in enumerate(ins) if l.startswith(("global_store", "buffer_store"))]
     between = 0
     if stores:
         # output rounds = runs of stores without an s_barrier in between
@@ -62,8 +62,30 @@ def report(name, ins, spills):
         runs.append(cur)
         longest = max(runs, key=len)
         drains = sum(1 for l in ins[longest[0]:longest[-1]] if re.match(r"s_waitcnt\s+vmcnt\(0\)", l))
+    # round 5: a VALU write to the data registers of a 16-byte store in the very next issue slot.  hipcc leaves no wait state there when the
+    # store carries an SGPR offset, and gfx950 then stores half-overwritten data (k_wino43.hip::wino43_output): must be 0
+    hazard = 0
+    for i, l in enumerate(ins[:-1]):
+        m = re.match(r"(?:buffer|global)_store_dwordx[34] (?:v\d+, |v\[\d+:\d+\], )?v\[(\d+):(\d+)\]", l) or re.match(r"buffer_store_dwordx[34] v\[(\d+):(\d+)\]", l)
+        w = re.match(r"v_\w+ v\[?(\d+)(?::(\d+))?\]?", ins[i + 1])
+        if m and w:
+            a, b, lo = int(m.group(1)), int(m.group(2)), int(w.group(1))
+            hi = int(w.group(2) or lo)
+            if not (hi < a or lo > b):
+                hazard += 1
+    valu = sum(1 for l in ins if l.startswith("v_") and not l.startswith("v_mfma"))
+    scr_loop = 0
+    if mf:
+        scr_loop = sum(1 for l in ins[longest[0]:longest[-1]] if l.startswith("scratch_"))
     return dict(kernel=name, spilled_vgprs=spills, scratch_reloads_between_output_stores=between, vmcnt0_inside_plane_loop=drains,
-                mfma=len(mf), stores=len(stores))
+                mfma=len(mf), stores=len(stores), store_data_overwritten_next_slot=hazard, scratch_in_plane_loop=scr_loop, valu=valu, v_mov=sum(1 for l in ins if l.startswith("v_mov")), v_pk=sum(1 for l in ins if l.startswith("v_pk_")),
+                ds=sum(1 for l in ins if l.startswith("ds_")))
+
+
+def file_flags(src):
+    """the per-file flags of the shipped build (csrc/Makefile: FLAGS_<stem> = ...)"""
+    m = re.search(r"^FLAGS_%s\s*=\s*(.*)$" % re.escape(src[:-4]), open(os.path.join(CS, "Makefile")).read(), re.M)
+    return (m.group(1).split() if m else []) + os.environ.get("BX_LINT_FLAGS", "").split()      # BX_LINT_FLAGS: variant builds
 
 
 def main():
@@ -71,7 +93,7 @@ def main():
     for src in ("k_wino43.hip", "k_wino43v.hip"):
         with tempfile.TemporaryDirectory() as td:
             out = os.path.join(td, "k.s")
-            subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + ["-o", out, os.path.join(CS, src)], check=True, stderr=subprocess.DEVNULL)
+            subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + file_flags(src) + ["-o", out, os.path.join(CS, src)], check=True, stderr=subprocess.DEVNULL)
             asm = open(out).read()
         spills = dict(zip(re.findall(r"^\s+\.name:\s+(_Z\w+)", asm, re.M), [int(v) for v in re.findall(r"\.vgpr_spill_count:\s+(\d+)", asm)]))
         for name, ins in kernels(asm).items():
@@ -80,8 +102,11 @@ def main():
             short = re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", name)[:48]
             r = report(short, ins, spills.get(name, -1))
             print(r)
+            if r["store_data_overwritten_next_slot"]:
+                bad += 1
             if src == "k_wino43.hip" and "Li64ELi64" in name and (r["scratch_reloads_between_output_stores"] or r["vmcnt0_inside_plane_loop"]):
                 bad += 1
+
     return 1 if bad else 0
 
 
