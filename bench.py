@@ -153,7 +153,7 @@ def main():
     ap.add_argument("--cost-l0", default=None, choices=["collapsed", "direct"], help="bx_params.cost_l0_form")
     ap.add_argument("--inflight-sweep", default="1,2,4,8,16", help="pairs in flight of the throughput-vs-latency sweep after the timed region ('' = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--e2e-pairs", type=int, default=24, help="pairs of the file-driven end-to-end measurement per RNG mode (0 = skip; N = 1 only)")
+    ap.add_argument("--e2e-pairs", type=int, default=96, help="pairs of the file-driven end-to-end measurement per RNG mode (0 = skip; N = 1 only); 96 = the step count of the hot-path measurement it is compared with (round 4 ran 24: fill and drain of 16 pairs in flight were a third of that run)")
     ap.add_argument("--num-fps", type=int, default=5000)
     ap.add_argument("--latency-tiles", type=int, default=2, help="keypoint tiles of the latency-form measurement (0/1 = skip it)")
     ap.add_argument("--ppp", type=int, default=1024)

@@ -152,6 +152,11 @@ void carve(bx_ctx* c, char* base, size_t* total)
     c->fps_dist = nullptr;
     c->fps_slots = cv.take<unsigned long long>(2 * 2 * 64 * 8);      // k_fps.hip: [cloud][parity][FPS_MAX_G][FPS_REC]
     c->fps_hello = cv.take<unsigned long long>(2 * 64);
+    c->fps_ord = cv.take<int32_t>(2 * NMAX);
+    c->fps_cell = cv.take<unsigned short>(2 * NMAX);
+    c->fps_cnt = cv.take<int>(2 * 4096 + 8);
+    c->fps_bbmax = reinterpret_cast<unsigned*>(c->fps_cnt + 2 * 4096);     // zeroed together with the counters
+    c->fps_bbmin = cv.take<unsigned>(8);
     c->ransac_inl = cv.take<int32_t>(BX_RANSAC_BATCH);
     c->ransac_err = cv.take<double>(BX_RANSAC_BATCH);
     c->ransac_T = cv.take<double>((size_t)BX_RANSAC_BATCH * 12);

@@ -148,6 +148,10 @@ struct bx_ctx {
     float* fps_dist;                    // [2][max_points]  (unused by register path; kept for generic path)
     unsigned long long* fps_slots;      // cross-workgroup exchange granules
     unsigned long long* fps_hello;      // [2][64] placement handshake granules (k_fps.hip)
+    int32_t* fps_ord;                   // [2][max_points] spatial order of the two clouds (bucket pruning, k_fps.hip)
+    unsigned short* fps_cell;           // [2][max_points] Morton cell of every point
+    int* fps_cnt;                       // [2][4096] cell counters, then fps_bbmax [8]
+    unsigned *fps_bbmin, *fps_bbmax;    // [2][4] encoded bounding boxes
     int fps_attr_set;
     int fps_xcd_pair;                   // 0..3: the XCD pair {2p, 2p+1} the co-located FPS launches of this context aim at; -1 until its first FPS launch
     int32_t* ransac_inl;                // [RANSAC_BATCH]

@@ -25,6 +25,16 @@
 //     if all G ids agree do they switch to the L2 protocol -- plain write-through stores, polls = buffer_inv sc1 + plain load --
 //     which never leaves the XCD's L2 (measured all-to-all round, G = 3: 0.57 us against 1.12 us across XCDs).  Any other
 //     placement keeps the agent-scope protocol: correctness never depends on where the blocks run.
+//   * bucket pruning (round 5; exact).  The per-iteration scan is bound by VALU issue (4 waves per SIMD run ~12 instructions per point),
+//     not by one wave's latency, so work that is skipped is time saved.  A pre-pass orders the cloud along a Morton curve of 16^3 cells
+//     (count / scan / scatter: bxk_fps_order) and a WAVE owns 64 x PPT points that are consecutive in that order -- a spatially compact
+//     BUCKET whose bounding box it holds in SGPRs.  A new sample c can lower the running min-distance of a bucket's point only if
+//     d2(c, box) < the bucket's largest min-distance: the box distance is built from the same rounded operations as the point
+//     distances, ((dx*dx + dy*dy) + dz*dz) with |dx| of the box <= |dx| of every point inside, and fp32 rounding is monotone, so
+//     d2(c, box) <= the COMPUTED d2(c, p) of every point of the bucket -- no margin is needed and the result is the un-pruned one bit
+//     for bit (all FPS parity tests run through this path; BX_FPS_PRUNE=0 scans every bucket every iteration).  A skipped bucket
+//     re-publishes its cached winner.  Buckets are dealt round-robin to the workgroups and waves of a cloud (bucket b -> workgroup
+//     b % G, wave b / G), so that the few buckets near a new sample sit on different SIMDs.
 #include "bx_common.h"
 
 namespace {
@@ -53,6 +63,8 @@ struct FpsArgs {
     unsigned long long* hello;  // [cloud][FPS_MAX_G] placement handshake granules, zeroed in front of every launch
     long long* dbg;             // BX_FPS_TRACE: cycle stamps of iterations 1000..1007 of workgroup 0 ([8][8])
     int32_t* err_flag;
+    const int32_t* ord[FPS_MAX_CLOUDS];   // [n] point index at every position of the Morton-cell order (bxk_fps_order)
+    int prune;                  // 1: skip the buckets a new sample cannot change
 };
 
 struct Rec {
@@ -99,6 +111,40 @@ __device__ __forceinline__ long long wave_max_key(long long key)
     return (long long)(((unsigned long long)(unsigned)mh << 32) | ml);
 }
 
+// the same over lanes 0..15 only (the 16 wave records of a workgroup, the records of <= 16 workgroups): four row_shr steps, result in
+// lane 15 -- the two row_bcast steps of the full reduction are two dependent DPP operations on the one wave that is on the critical path
+__device__ __forceinline__ int row_max_i32(int v)
+{
+    const int id = (int)0x80000000;
+    int o;
+    o = __builtin_amdgcn_update_dpp(id, v, 0x111, 0xf, 0xf, false); v = o > v ? o : v;
+    o = __builtin_amdgcn_update_dpp(id, v, 0x112, 0xf, 0xf, false); v = o > v ? o : v;
+    o = __builtin_amdgcn_update_dpp(id, v, 0x114, 0xf, 0xf, false); v = o > v ? o : v;
+    o = __builtin_amdgcn_update_dpp(id, v, 0x118, 0xf, 0xf, false); v = o > v ? o : v;
+    return __builtin_amdgcn_readlane(v, 15);
+}
+__device__ __forceinline__ unsigned row_max_u32(unsigned v)
+{
+    unsigned o;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); v = o > v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); v = o > v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); v = o > v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); v = o > v ? o : v;
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 15);
+}
+// lanes >= 16 must hold the identity (0x8000...0)
+__device__ __forceinline__ long long row_max_key(long long key)
+{
+    const int hi = (int)(key >> 32);
+    const unsigned lo = (unsigned)((unsigned long long)key & 0xffffffffu);
+    const int mh = row_max_i32(hi);
+    const unsigned long long bal = __ballot(hi == mh) & 0xffffULL;
+    unsigned ml;
+    if ((bal & (bal - 1ULL)) == 0ULL) ml = (unsigned)__builtin_amdgcn_readlane((int)lo, __ffsll((long long)bal) - 1);
+    else ml = row_max_u32(hi == mh ? lo : 0u);
+    return (long long)(((unsigned long long)(unsigned)mh << 32) | ml);
+}
+
 __device__ __forceinline__ unsigned xcc_id()
 {
     unsigned v;
@@ -126,6 +172,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
     __shared__ float s_xyz[2][FPS_WAVES][3];
     __shared__ long long s_fkey[2];
     __shared__ float s_fxyz[2][3];
+    __shared__ int s_slot[2][FPS_WAVES];           // local slot (i * 1024 + t) of every wave's winner: its coordinates sit in s_pts
 
     int cloud = 0, g;
     if (a.colocate) {
@@ -143,8 +190,10 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
     const int n = a.n[cloud];
     const float* __restrict__ xyz = a.xyz[cloud];
     const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
-    const int base = g * (FPS_THREADS * PPT);
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int32_t* __restrict__ ord = a.ord[cloud];
+    // bucket of this wave: 64 x PPT consecutive positions of the spatial order; buckets dealt round-robin over (workgroup, wave)
+    const int sp0 = (wave * G + g) * (64 * PPT) + lane;
 
     int T = 1, lt = 0;
     while (T * 2 <= n && T * 2 <= 512) { T *= 2; ++lt; }
@@ -156,18 +205,24 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
     constexpr int NP = PPT * FPS_THREADS;
     extern __shared__ float s_pts[];
     float px[PPT], py[PPT], pz[PPT], td[PPT];
+    unsigned pt[PPT];                              // low word of the point's key = ~tie-break(k): the tie rule, and k itself (invertible)
+    float lox = 3.0e38f, loy = 3.0e38f, loz = 3.0e38f, hix = -3.0e38f, hiy = -3.0e38f, hiz = -3.0e38f;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-        int k = base + i * FPS_THREADS + t;
-        if (k < n) {
+        const int sp = sp0 + i * 64;
+        if (sp < n) {
+            const int k = ord ? ord[sp] : sp;
+            pt[i] = ~((((unsigned)k & tmask) << 23) | ((unsigned)k >> lt));
             px[i] = xyz[(size_t)k * 3 + 0];
             py[i] = xyz[(size_t)k * 3 + 1];
             pz[i] = xyz[(size_t)k * 3 + 2];
             float mag = (px[i] * px[i] + py[i] * py[i]) + pz[i] * pz[i];
             td[i] = (mag <= 1e-3f) ? -1.0f : 1e10f;  // -1 marks "never a candidate" (upstream `continue`)
             if (a.j0 > 0) td[i] = a.td_state[cloud][k];
+            lox = fminf(lox, px[i]); loy = fminf(loy, py[i]); loz = fminf(loz, pz[i]);
+            hix = fmaxf(hix, px[i]); hiy = fmaxf(hiy, py[i]); hiz = fmaxf(hiz, pz[i]);
         } else {
-            px[i] = 0.f; py[i] = 0.f; pz[i] = 0.f; td[i] = -1.0f;
+            pt[i] = 0u; px[i] = 0.f; py[i] = 0.f; pz[i] = 0.f; td[i] = -1.0f;
         }
         if (LDSXYZ) {
             s_pts[i * FPS_THREADS + t] = px[i];
@@ -175,11 +230,19 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
             s_pts[2 * NP + i * FPS_THREADS + t] = pz[i];
         }
     }
-    // local slot (= k - base) of the point a key names
-    auto key_slot = [&](long long kk) -> int {
-        const unsigned tbw = ~(unsigned)((unsigned long long)kk & 0xffffffffu);
-        return (int)(((tbw & 0x7fffffu) << lt) | (tbw >> 23)) - base;
-    };
+    // the bucket's bounding box (wave-uniform: SGPRs); an empty bucket keeps lo > hi and is never scanned (all its td are -1)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lox = fminf(lox, __shfl_xor(lox, o)); loy = fminf(loy, __shfl_xor(loy, o)); loz = fminf(loz, __shfl_xor(loz, o));
+        hix = fmaxf(hix, __shfl_xor(hix, o)); hiy = fmaxf(hiy, __shfl_xor(hiy, o)); hiz = fmaxf(hiz, __shfl_xor(hiz, o));
+    }
+    lox = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(lox))); loy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(loy)));
+    loz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(loz))); hix = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hix)));
+    hiy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hiy))); hiz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hiz)));
+    float wmax = 3.0e38f;                          // the bucket's largest running min-distance: unknown -> the first iteration scans
+    long long wk_c = (long long)0x8000000000000000LL;   // cached winner of the bucket {key, local slot | coordinates}
+    int ws_c = 0;
+    float wx_c = 0.f, wy_c = 0.f, wz_c = 0.f;
     float cx = xyz[0], cy = xyz[1], cz = xyz[2];
     if (a.j0 > 0) {   // the previous launch of this stream wrote the last keypoint (kernel boundary: visible)
         const float* lk = a.kpts_out[cloud] + (size_t)(a.j0 - 1) * 3;
@@ -225,55 +288,100 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
         long long* tdp = a.dbg + (j - 1000) * 8;
 #define FPS_TR(q) do { if (tr) tdp[q] = __builtin_readcyclecounter(); } while (0)
         FPS_TR(0);
-        float bd = -1.0f, bx = 0.f, by = 0.f, bz = 0.f;
-        int bi = 0;
+        // can the new sample lower any running min-distance of this bucket?  d2(c, box), from the same rounded operations as the
+        // point distances below (monotone: <= the computed distance of every point inside the box)
+        bool scan = true;
+        if (a.prune) {
+            const float ex = fmaxf(fmaxf(lox - cx, cx - hix), 0.0f), ey = fmaxf(fmaxf(loy - cy, cy - hiy), 0.0f), ez = fmaxf(fmaxf(loz - cz, cz - hiz), 0.0f);
+            const float db = (ex * ex + ey * ey) + ez * ez;
+            scan = __builtin_amdgcn_readfirstlane(db < wmax ? 1 : 0) != 0;
+        }
+        if (scan) {
+            float bd = -1.0f, bx = 0.f, by = 0.f, bz = 0.f;
+            int bi = 0;
+            bool tie = false;
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            float dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz;
-            float d = (dx * dx + dy * dy) + dz * dz;
-            float d2 = fminf(d, td[i]);
-            td[i] = d2;
-            bool better = d2 > bd;
-            bd = better ? d2 : bd;
-            bi = better ? i : bi;
-            if (!LDSXYZ) {
-                bx = better ? px[i] : bx;
-                by = better ? py[i] : by;
-                bz = better ? pz[i] : bz;
+            for (int i = 0; i < PPT; ++i) {
+                float dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz;
+                float d = (dx * dx + dy * dy) + dz * dz;
+                float d2 = fminf(d, td[i]);
+                td[i] = d2;
+                bool better = d2 > bd;
+                tie = tie || (d2 == bd);               // an equal distance inside one thread: decided by the key order below
+                bd = better ? d2 : bd;
+                bi = better ? i : bi;
+                if (!LDSXYZ) {
+                    bx = better ? px[i] : bx;
+                    by = better ? py[i] : by;
+                    bz = better ? pz[i] : bz;
+                }
+            }
+            unsigned bt = pt[0];
+#pragma unroll
+            for (int i = 1; i < PPT; ++i) bt = bi == i ? pt[i] : bt;
+            if (__any(tie)) {
+                // a thread's points are no longer one residue class of the upstream thread stride (they were k = base + i * 1024 + t before
+                // the spatial order), so "first maximum of the thread" is not the upstream winner when two of them tie: take the larger KEY
+                // (equal distance: lower k mod T, then lower k).  Rare: exact fp32 ties, and threads that hold several non-candidates.
+                bd = td[0]; bi = 0; bt = pt[0];
+#pragma unroll
+                for (int i = 1; i < PPT; ++i) {
+                    const bool better = td[i] > bd || (td[i] == bd && pt[i] > bt);
+                    bd = better ? td[i] : bd; bt = better ? pt[i] : bt; bi = better ? i : bi;
+                }
+                if (!LDSXYZ) {
+                    bx = px[0]; by = py[0]; bz = pz[0];
+#pragma unroll
+                    for (int i = 1; i < PPT; ++i) { bx = bi == i ? px[i] : bx; by = bi == i ? py[i] : by; bz = bi == i ? pz[i] : bz; }
+                }
+            }
+            long long key = ((long long)__float_as_int(bd) << 32) | (long long)bt;
+            // wave max (signed 64-bit) on the DPP network
+            const long long wk = wave_max_key(key);
+            // keys are unique per thread (they embed the point index): the winner's lane broadcasts its slot / coordinates
+            const int wl = __ffsll((long long)__ballot(key == wk)) - 1;
+            wk_c = wk;
+            wmax = __int_as_float((int)(wk >> 32));            // the bucket's largest min-distance (-1: no candidate left)
+            if (LDSXYZ) {
+                ws_c = __builtin_amdgcn_readlane(bi * FPS_THREADS + t, wl);
+            } else {
+                wx_c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx), wl));
+                wy_c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(by), wl));
+                wz_c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bz), wl));
             }
         }
         FPS_TR(1);
-        unsigned k = (unsigned)(base + bi * FPS_THREADS + t);
-        unsigned tb = ((k & tmask) << 23) | (k >> lt);
-        long long key = ((long long)__float_as_int(bd) << 32) | (long long)(unsigned)(~tb);
-        // wave max (signed 64-bit) on the DPP network
-        const long long wk = wave_max_key(key);
-        if (key == wk) {  // keys are unique per thread (they embed the point index)
-            s_key[par][wave] = wk;
-            if (!LDSXYZ) { s_xyz[par][wave][0] = bx; s_xyz[par][wave][1] = by; s_xyz[par][wave][2] = bz; }
+        long long fk;
+        float fx, fy, fz;
+        {
+        if (lane == 0) {
+            s_key[par][wave] = wk_c;
+            if (LDSXYZ) s_slot[par][wave] = ws_c;
+            else { s_xyz[par][wave][0] = wx_c; s_xyz[par][wave][1] = wy_c; s_xyz[par][wave][2] = wz_c; }
         }
         FPS_TR(2);
         __syncthreads();
         FPS_TR(3);
-        long long fk;
-        float fx, fy, fz;
         if (G == 1) {
             fk = s_key[par][0]; fx = s_xyz[par][0][0]; fy = s_xyz[par][0][1]; fz = s_xyz[par][0][2];
+            int fs = s_slot[par][0];
 #pragma unroll
             for (int w = 1; w < FPS_WAVES; ++w) {
                 long long kk = s_key[par][w];
                 bool b = kk > fk;
                 fk = b ? kk : fk;
+                fs = b ? s_slot[par][w] : fs;
                 fx = b ? s_xyz[par][w][0] : fx;
                 fy = b ? s_xyz[par][w][1] : fy;
                 fz = b ? s_xyz[par][w][2] : fz;
             }
-            if (LDSXYZ) { const int sl = key_slot(fk); fx = s_pts[sl]; fy = s_pts[NP + sl]; fz = s_pts[2 * NP + sl]; }
+            if (LDSXYZ) { fx = s_pts[fs]; fy = s_pts[NP + fs]; fz = s_pts[2 * NP + fs]; }
         } else {
             if (wave == 0) {
                 // combine the 16 wave records
                 long long k0 = lane < FPS_WAVES ? s_key[par][lane] : (long long)0x8000000000000000LL;
-                const long long mk = wave_max_key(k0);
+                static_assert(FPS_WAVES == 16, "row reduction over the 16 wave records");
+                const long long mk = row_max_key(k0);
                 // the (unique, or lowest) lane holding the max publishes this workgroup's record
                 unsigned long long bal = __ballot(lane < FPS_WAVES && k0 == mk);
                 int src = __ffsll((long long)bal) - 1;
@@ -281,7 +389,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                 {   // lanes 0..4 store one granule each: one store instruction, one 40-byte write
                     unsigned sx, sy, sz;
                     if (LDSXYZ) {
-                        const int sl = key_slot(mk);
+                        const int sl = s_slot[par][src];
                         sx = __float_as_uint(s_pts[sl]); sy = __float_as_uint(s_pts[NP + sl]); sz = __float_as_uint(s_pts[2 * NP + sl]);
                     } else {
                         sx = __float_as_uint(s_xyz[par][src][0]); sy = __float_as_uint(s_xyz[par][src][1]);
@@ -331,7 +439,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                 FPS_TR(5);
                 if (fail && lane == 0) atomicOr(a.err_flag, 1);
                 const long long rk = lane < G ? (long long)(((unsigned long long)(unsigned)r0 << 32) | (unsigned)r1) : (long long)0x8000000000000000LL;
-                const long long bestk = wave_max_key(rk);
+                const long long bestk = G <= 16 ? row_max_key(rk) : wave_max_key(rk);
                 // keys embed the point index: one lane holds the maximum (the lowest one, should two ever agree)
                 const int wl = __ffsll((long long)__ballot(lane < G && rk == bestk)) - 1;
                 const float ox = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)(unsigned)r2, wl));
@@ -346,6 +454,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
             __syncthreads();
             fk = s_fkey[par]; fx = s_fxyz[par][0]; fy = s_fxyz[par][1]; fz = s_fxyz[par][2];
             FPS_TR(7);
+        }
         }
         int old;
         if (fk < 0) {  // no candidate anywhere (all points within 1e-3 of the origin): upstream yields index 0
@@ -366,11 +475,89 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
     }
     if (a.save) {
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            int k = base + i * FPS_THREADS + t;
-            if (k < n) a.td_state[cloud][k] = td[i];
-        }
+        for (int i = 0; i < PPT; ++i)
+            if (sp0 + i * 64 < n) {
+                const unsigned tbw = ~pt[i];
+                a.td_state[cloud][(int)(((tbw & 0x7fffffu) << lt) | (tbw >> 23))] = td[i];
+            }
     }
+}
+
+// ---- spatial order of a cloud (bucket pruning): Morton curve over 16 x 16 x 16 cells of the bounding box, counting sort.  The order
+//      inside a cell is whatever the atomics produce -- it decides which bucket a point sits in, never the sampling result.
+struct OrderArgs {
+    const float* xyz[FPS_MAX_CLOUDS];
+    int n[FPS_MAX_CLOUDS];
+    unsigned* bbmin[FPS_MAX_CLOUDS];    // [3] encoded min x, y, z (memset 0xff)
+    unsigned* bbmax[FPS_MAX_CLOUDS];    // [3] encoded max x, y, z (memset 0)
+    int* cnt[FPS_MAX_CLOUDS];           // [4096] points per cell -> exclusive start -> fill cursor
+    unsigned short* cell;               // [2][max_points] Morton cell of every point
+    int32_t* ord[FPS_MAX_CLOUDS];       // [n]
+    int stride;                         // max_points
+};
+constexpr int FPS_CELLS = 4096;
+__device__ __forceinline__ unsigned fenc(float f) { const unsigned b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }   // monotone
+__device__ __forceinline__ float fdec(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+__device__ __forceinline__ unsigned spread4(unsigned v) { return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6); }   // bit i -> bit 3 i
+
+__global__ __launch_bounds__(256) void fps_bbox_kernel(OrderArgs a)
+{
+    const int c = blockIdx.y, n = a.n[c];
+    const float* __restrict__ p = a.xyz[c];
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { const float v = p[(size_t)k * 3 + d]; lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v); }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo[d] = fminf(lo[d], __shfl_xor(lo[d], o)); hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(a.bbmin[c] + d, fenc(lo[d])); atomicMax(a.bbmax[c] + d, fenc(hi[d])); }
+    }
+}
+__global__ __launch_bounds__(256) void fps_cell_kernel(OrderArgs a)
+{
+    const int c = blockIdx.y, n = a.n[c];
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    unsigned q[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float lo = fdec(a.bbmin[c][d]), hi = fdec(a.bbmax[c][d]);
+        const float w = hi - lo;
+        const float s = w > 0.f ? 16.0f / w : 0.f;
+        int v = (int)((a.xyz[c][(size_t)k * 3 + d] - lo) * s);
+        q[d] = (unsigned)(v < 0 ? 0 : (v > 15 ? 15 : v));
+    }
+    const unsigned cell = spread4(q[0]) | (spread4(q[1]) << 1) | (spread4(q[2]) << 2);
+    a.cell[(size_t)c * a.stride + k] = (unsigned short)cell;
+    atomicAdd(a.cnt[c] + cell, 1);
+}
+__global__ __launch_bounds__(1024) void fps_cell_scan_kernel(OrderArgs a)
+{
+    __shared__ int s_w[16];
+    const int c = blockIdx.x, t = threadIdx.x;
+    int* cnt = a.cnt[c];
+    int v[4], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = cnt[t * 4 + i]; sum += v[i]; }
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if ((t & 63) >= o) inc += u; }
+    if ((t & 63) == 63) s_w[t >> 6] = inc;
+    __syncthreads();
+    int base = inc - sum;
+    for (int w = 0; w < (t >> 6); ++w) base += s_w[w];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { cnt[t * 4 + i] = base; base += v[i]; }
+}
+__global__ __launch_bounds__(256) void fps_scatter_kernel(OrderArgs a)
+{
+    const int c = blockIdx.y, n = a.n[c];
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int pos = atomicAdd(a.cnt[c] + a.cell[(size_t)c * a.stride + k], 1);
+    a.ord[c][pos] = k;
 }
 
 __global__ void gather_rows_kernel(const float* __restrict__ pts, const int32_t* __restrict__ idx, int n, float* __restrict__ out)
@@ -448,6 +635,31 @@ int bxk_fps_range(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* 
     }
     // epochs continue across the launches of a tiled run: the slots are cleared once, in front of the first one
     if (j0 == 0) BX_HIP(hipMemsetAsync(c->fps_slots, 0, sizeof(unsigned long long) * FPS_MAX_CLOUDS * 2 * FPS_MAX_G * FPS_REC, s));
+    // the spatial order of the clouds (bucket pruning), once per run
+    {
+        const char* ep = getenv("BX_FPS_PRUNE");       // test / measurement hook: 0 = scan every bucket in every iteration
+        a.prune = ep ? atoi(ep) : 1;
+        // a cloud beyond the context's max_points (stage entry point only: bx_register_pair checks its clouds) has no room for its order:
+        // it is sampled in input order -- buckets that are not compact are rarely skipped, the result is the same
+        bool ordered = true;
+        for (int i = 0; i < nclouds; ++i) ordered = ordered && n[i] <= c->p.max_points;
+        for (int i = 0; i < nclouds; ++i) a.ord[i] = ordered ? c->fps_ord + (size_t)i * c->p.max_points : nullptr;
+        if (j0 == 0 && ordered) {
+            OrderArgs o{};
+            for (int i = 0; i < nclouds; ++i) {
+                o.xyz[i] = xyz[i]; o.n[i] = n[i];
+                o.bbmin[i] = c->fps_bbmin + 4 * i; o.bbmax[i] = c->fps_bbmax + 4 * i; o.cnt[i] = c->fps_cnt + FPS_CELLS * i;
+                o.ord[i] = c->fps_ord + (size_t)i * c->p.max_points;
+            }
+            o.cell = c->fps_cell; o.stride = c->p.max_points;
+            BX_HIP(hipMemsetAsync(c->fps_cnt, 0, sizeof(int) * (FPS_CELLS * FPS_MAX_CLOUDS + 8), s));    // cell counters + fps_bbmax (carved behind them)
+            BX_HIP(hipMemsetAsync(c->fps_bbmin, 0xff, sizeof(unsigned) * 8, s));
+            hipLaunchKernelGGL(fps_bbox_kernel, dim3(32, nclouds), dim3(256), 0, s, o);
+            hipLaunchKernelGGL(fps_cell_kernel, dim3((nmax + 255) / 256, nclouds), dim3(256), 0, s, o);
+            hipLaunchKernelGGL(fps_cell_scan_kernel, dim3(nclouds), dim3(1024), 0, s, o);
+            hipLaunchKernelGGL(fps_scatter_kernel, dim3((nmax + 255) / 256, nclouds), dim3(256), 0, s, o);
+        }
+    }
     const size_t lds = ppt <= 8 ? (size_t)3 * ppt * FPS_THREADS * sizeof(float) : 0;     // PPT 8: 96 KiB
     if (lds > 48 * 1024 && !c->fps_attr_set) {
         BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));

@@ -81,6 +81,24 @@ def make_perm(n, seed, stream):
     return np.argsort(keys, kind="stable").astype(np.int32)
 
 
+class distance_form:
+    """`with oracle.distance_form("nvcc_fma"): ...` -- the STUDY switch of bx_oracle.c (squared distances of FPS / ball query / SPT as
+    nvcc's default contraction would evaluate them); the contract, and the product, are "unfused"."""
+    FORMS = ("unfused", "nvcc_fma")
+
+    def __init__(self, name):
+        self.new = self.FORMS.index(name)
+
+    def __enter__(self):
+        L = lib()
+        self.old = int(L.bxo_get_distance_form())
+        L.bxo_set_distance_form(C.c_int(self.new))
+        return self
+
+    def __exit__(self, *a):
+        lib().bxo_set_distance_form(C.c_int(self.old))
+
+
 def fps(xyz, m):
     xyz = _f(xyz)
     idx = np.zeros(m, np.int32)

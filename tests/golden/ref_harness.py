@@ -14,6 +14,7 @@ numpy, numpy SVD) so that oracle-vs-golden agreement is a real cross-check:
 Randomness the reference leaves unseeded is made explicit: np.random.choice inside select_patches is
 served from a queue of permutations, the RANSAC stub uses the counter RNG of the C-ABI contract.
 """
+import os
 import sys
 import types
 import numpy as np
@@ -36,6 +37,23 @@ def make_perm(n, seed, stream):
 
 
 # ---------------------------------------------------------------- pointnet2_ops stubs
+# BX_REF_DIST_FORM=nvcc_fma (round 5, a study switch): squared distances as nvcc's default -fmad=true contracts the upstream kernels'
+# source expression, fmaf(dz, dz, fmaf(dy, dy, dx * dx)); default = the un-fused evaluation.  fmaf is emulated in binary64 (the product
+# of two binary32 numbers is exact there; the one extra rounding of the sum can differ from a true fmaf only when the exact result lies
+# within 2^-29 ulp of a binary32 tie -- the C oracle uses the hardware instruction, and the two are compared).
+DIST_FORM = os.environ.get("BX_REF_DIST_FORM", "unfused")
+
+
+def _fma32(a, b, c):
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+
+def _d2(dx, dy, dz):
+    if DIST_FORM == "nvcc_fma":
+        return _fma32(dz, dz, _fma32(dy, dy, dx * dx))
+    return (dx * dx + dy * dy) + dz * dz
+
+
 def _fps_np(xyz, m):
     xyz = np.asarray(xyz, np.float32)
     n = len(xyz)
@@ -43,7 +61,7 @@ def _fps_np(xyz, m):
     while T * 2 <= n and T * 2 <= 512:
         T *= 2
     temp = np.full(n, 1e10, np.float32)
-    mag = (xyz[:, 0] * xyz[:, 0] + xyz[:, 1] * xyz[:, 1]) + xyz[:, 2] * xyz[:, 2]
+    mag = _d2(xyz[:, 0], xyz[:, 1], xyz[:, 2])
     ok = ~(mag <= np.float32(1e-3))
     ar = np.arange(n)
     tid = ar % T
@@ -51,7 +69,7 @@ def _fps_np(xyz, m):
     old = 0
     for j in range(1, m):
         d = xyz - xyz[old]
-        d = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        d = _d2(d[:, 0], d[:, 1], d[:, 2])
         temp = np.where(ok, np.minimum(d, temp), temp)
         if not ok.any():
             old = 0
@@ -71,7 +89,7 @@ def _ball_query_np(r, ns, xyz, new_xyz):
     out = np.zeros((len(new_xyz), ns), np.int32)
     for j, q in enumerate(new_xyz):
         d = q - xyz
-        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        d2 = _d2(d[:, 0], d[:, 1], d[:, 2])
         hit = np.flatnonzero(d2 < r2)[:ns]
         if len(hit):
             out[j, :] = hit[0]

@@ -51,11 +51,14 @@ def test_fps_exact(ctx, oracle, n, m):
 
 @pytest.mark.parametrize("colocate", ["0", "1"])
 @pytest.mark.parametrize("ppt", ["4", "8", "16"])
-def test_fps_protocols_and_tilings(ctx, oracle, monkeypatch, colocate, ppt):
-    """Both exchange protocols (XCD co-located L2 granules / agent-scope granules in dispatch-order placement) and every
-    points-per-thread instantiation give the oracle's indices, ties included (BX_FPS_COLOCATE / BX_FPS_PPT are test hooks)."""
+@pytest.mark.parametrize("prune", ["1", "0"])
+def test_fps_protocols_and_tilings(ctx, oracle, monkeypatch, colocate, ppt, prune):
+    """Both granule protocols (XCD co-located L2 granules / agent-scope granules in dispatch-order placement), bucket pruning on and off
+    (round 5) and every points-per-thread instantiation give the oracle's indices, ties included (BX_FPS_COLOCATE / BX_FPS_PPT /
+    BX_FPS_PRUNE are test hooks)."""
     monkeypatch.setenv("BX_FPS_COLOCATE", colocate)
     monkeypatch.setenv("BX_FPS_PPT", ppt)
+    monkeypatch.setenv("BX_FPS_PRUNE", prune)
     rng = np.random.default_rng(7)
     xyz = (rng.random((40000, 3), np.float32) * 4 - 1).astype(np.float32)
     xyz[1000:3000] = np.round(xyz[1000:3000] * 2) / 2          # a lattice block: exact distance ties across workgroups

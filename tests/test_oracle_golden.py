@@ -119,8 +119,8 @@ def test_oracle_pipeline_matches_reference(bx, packed, golden_dir, name):
 # smallest fraction of the sampled descriptor rows of one (scale, cloud) within 2e-5 of the reference's, per fixture: the z-aligned
 # configurations agree in every row; the un-aligned (indoor) ones have a few rows per thousand with a point within an ulp of a radius /
 # voxel bound
-BIG_ROWS_MIN_FRAC = {"headline_cfg1": 0.99, "kitti_cfg2": 0.99, "tiers_early": 0.99, "headline_cfg1_b": 0.99, "headline_cfg1_c": 0.99,
-                     "kitti_cfg2_b": 0.99, "headline_lo": 0.99}
+BIG_ROWS_MIN_FRAC = {"headline_cfg1": 0.997, "kitti_cfg2": 1.0, "tiers_early": 1.0, "headline_cfg1_b": 0.995, "headline_cfg1_c": 0.997,
+                     "kitti_cfg2_b": 1.0, "headline_lo": 0.996}     # observed 0.9976 / 1 / 1 / 0.9952 / 0.9976 / 1 / 0.9968 (of 1 250 rows)
 BIG_NAMES = ["headline_cfg1", "kitti_cfg2", "tiers_early", "headline_cfg1_b", "headline_cfg1_c", "kitti_cfg2_b", "headline_lo"]
 
 
