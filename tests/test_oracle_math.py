@@ -229,3 +229,29 @@ def test_collapsed_cost_layer_close_to_direct_form(oracle, bx, packed):
     coll = oracle.cost_l0(se, te, sm, tm, L0["W"], L0["b"])
     assert direct.shape == coll.shape == (m, 2, 972, 16)
     assert np.abs(direct - coll).max() < 3e-5 * max(1.0, float(np.abs(direct).max()))
+
+
+# ------------------------------------------------------------------ distance form study switch (round 5)
+def test_distance_form_switch(oracle, monkeypatch):
+    """The STUDY switch that evaluates the squared distances of FPS / ball_query the way nvcc contracts the upstream kernels
+    (fmaf(dz, dz, fmaf(dy, dy, dx * dx))): the C oracle (hardware fmaf) and the numpy stand-ins of tests/golden/ref_harness.py
+    (binary64 emulation) must agree with each other in both forms, the switch must restore the contract's form, and the two forms
+    must differ only where a distance sits within an ulp of a threshold or of another distance (profiles/r05_distance_form.jsonl has
+    the real-size count: 1 neighbour list of 30 000, no FPS index, no match)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import ref_harness as H
+    rng = np.random.default_rng(5)
+    pts = (rng.random((6000, 3), np.float32) * 3).astype(np.float32)
+    kp_idx = {}
+    for form in ("unfused", "nvcc_fma"):
+        monkeypatch.setattr(H, "DIST_FORM", form)
+        with oracle.distance_form(form):
+            a = oracle.fps(pts, 600)
+            kp = pts[a[:200]]
+            i, _ = oracle.ball_group(pts, kp, np.float32(0.31), 128)
+        assert np.array_equal(H._fps_np(pts, 600), a), form
+        assert np.array_equal(H._ball_query_np(0.31, 128, pts, kp), i), form
+        kp_idx[form] = (a, i)
+    assert int(oracle.lib().bxo_get_distance_form()) == 0          # the context manager restored the contract's form
+    assert (kp_idx["unfused"][0] != kp_idx["nvcc_fma"][0]).sum() <= 4
