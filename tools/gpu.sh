@@ -12,6 +12,7 @@
 #   stage:WHAT[,args...]    tools/bench_stage.py WHAT (ball | patch | conv | all)
 #   ubench:NAME             hipcc tools/ubench/NAME.hip && run it -> ubench_NAME.txt
 #   profile[:TAG]           rocprofv3 kernel-trace + the PMC passes of the bench command -> prof_TAG/ (summaries for profiles/)
+#   kstat:TAG,cmd...        rocprofv3 --kernel-trace --stats of `python <cmd with ',' -> ' '>` -> per-kernel table (top 25)
 #   env:VAR=VALUE           export VAR for the following steps (e.g. env:BX_HIP_SO=...)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
@@ -75,6 +76,12 @@ for step in "$@"; do
       $CMD > $P/bench_line.json 2> $P/bench_line.err
       find $P -name '*.csv' -size +3M -delete; find $P -name '*.db' -size +30M -delete
       head -70 $P/summary.txt; grep -E "desc_conv_stack|costnet" $P/mfma_busy.json;;
+    kstat)
+      tag=${arg%%,*}; rest=$(echo "${arg#*,}" | tr ',' ' ')
+      K=$OUT/kstat_$tag; rm -rf $K; mkdir -p $K
+      timeout 600 rocprofv3 --kernel-trace --stats -d $K/kt -o kt -- python $rest > $K/out.log 2>&1 < /dev/null
+      python tools/summarize_prof.py $K 2>/dev/null | head -27 | tee $K/summary.txt
+      find $K -name '*.csv' -size +3M -delete; find $K -name '*.db' -size +30M -delete;;
     *) echo "unknown step $what";;
   esac
 done
