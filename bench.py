@@ -36,10 +36,12 @@ PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 /
 PEAK_HBM_GBS = 8000.0            # HBM3E spec (6.29 TB/s measured achievable)
 DESC_CONV_MMAC_PER_PATCH = 3.871 + 5.161 + 10.322 + 20.644 + 10.322 + 5.161 + 2.580 + 1.290
 # what the kernels issue on the matrix pipe for the Desc stack, per form (bx_params.desc_conv_form):
-#  winograd43 (default, round 4: ALL eight layers): 36 planes x 32 tile rows (30 used) per three units = 384 / 1260 of the direct MACs
+#  winograd43 (default, ALL eight layers): 36 planes x 32 tile rows per 3.2 units = 360 / 1260 of the direct MACs (round 5: a workgroup
+#      item is 32 consecutive tile rows; round 4 issued 36 x 32 per THREE units = 384 / 1260, two of every 32 rows being padding -- the same
+#      kernel time now shows a 6 % LOWER issued-flop fraction although nothing got slower: the algorithmic rate below is the comparable one)
 #  winograd22: layers 0..5 (>= 64 output channels) 16 planes x 40 tile rows per two units = 640 / 1260, layers 6, 7 direct
 DESC_EXECUTED_MMAC_PER_PATCH = {
-    "winograd43": DESC_CONV_MMAC_PER_PATCH * 384.0 / 1260.0,
+    "winograd43": DESC_CONV_MMAC_PER_PATCH * 360.0 / 1260.0,
     "winograd22": (3.871 + 5.161 + 10.322 + 20.644 + 10.322 + 5.161) * 640.0 / 1260.0 + 2.580 + 1.290,
     "direct": DESC_CONV_MMAC_PER_PATCH,
 }
@@ -376,7 +378,7 @@ def main():
             form = forms["desc_conv"]
             ex_mmac = DESC_EXECUTED_MMAC_PER_PATCH[form]
             ex_ach = 2.0 * ex_mmac * 1e6 * K / (conv_ms / conv_n * 1e-3) / 1e12
-            roof = {"kernel": {"winograd43": "wino43_kernel<...> x8 (Winograd F(4x4,3x3), three units per workgroup; every layer)",
+            roof = {"kernel": {"winograd43": "wino43_kernel<...> x8 (Winograd F(4x4,3x3), items of 32 tile rows; every layer)",
                                "winograd22": "wino_pair_kernel<...> x6 (Winograd F(2x2,3x3), two units per workgroup) + conv_kernel<...> x2",
                                "direct": "conv_kernel<...> x8"}[form] + " (Cylindrical_Net stack, f32 MFMA)",
                     "bound": "mfma",

@@ -10,11 +10,14 @@
 // reference-minted fixtures are the judge.  Arithmetic contract: oracle/bx_oracle.c::bxo_conv_wino43; GPU == oracle bit for bit.
 //
 // Round-4 kernel (profiles/r04_wino43_variants.txt has the measurements behind every choice):
-//  * workgroup = 8 waves = CW output channels (64; 32 for the two 32-channel layers) of THREE units (30 tile rows = two MFMA row tiles);
+//  * workgroup = 8 waves = CW output channels (64; 32 for the two 32-channel layers) of one ITEM = 32 consecutive tile rows of the
+//    layer's (unit, tile) sequence = two full MFMA row tiles (round 5; rounds 3-4: three whole units = 30 of the 32 rows -- see the
+//    constants below: 6.7 % fewer items, +1.6 % pairs/s; the MFMAs no longer issued on two padding rows also lower the ISSUED-flop
+//    roofline fraction by 6 % at equal time: bench.py prices 360 instead of 384 plane-rows per unit);
 //    compute wave (column tile ct, half) owns the eighteen planes of the xi rows 3 half .. 3 half + 2: 36 accumulator tiles = 144 VGPRs.
 //    With CW = 32 only waves 0..3 (one per SIMD) stream MFMAs; the others still stage and transform.
-//  * slab: the (unit, chunk) maps arrive as 16-byte pieces (four per thread, non-temporal) in the LDS slab (10 x 22 positions per unit
-//    with the wrap-around columns copied and the rows beyond the map left zero).  Loads and the weight ring share ONE in-order counter
+//  * slab: the (unit, chunk) maps arrive as 16-byte pieces (up to five per thread, non-temporal) in the LDS slab (four unit slots of 9 x 22
+//    positions with the wrap-around columns copied and the rows beyond the map left zero).  Loads and the weight ring share ONE in-order counter
 //    (vmcnt), so the pieces of the next chunk are requested right after the chunk's first barrier -- a transform and a whole MFMA phase
 //    before they are needed, never between two ring loads -- and written to the slab all at once behind the last plane (the write's
 //    wait for its piece is a wait for every load in flight: one such drain per chunk, under the tail of the MFMAs).
@@ -54,15 +57,23 @@ using namespace w43;
 constexpr int WP = BX_AZI + 2;                   // slab columns (wrap-around halo)
 constexpr int HP = BX_ELE + 3;                   // slab rows h = -1 .. 8 (tile row 1 reaches two rows below the map)
 constexpr int TR4 = (BX_ELE + 3) / 4, TC4 = BX_AZI / 4, NT4 = TR4 * TC4;   // 2 x 5 = 10 tiles
-constexpr int G4 = 3, ROWS4 = G4 * NT4;          // three units = 30 tile rows of the 32
-constexpr int RP3 = WP * ROWF + 4, UP3 = HP * RP3;                         // slab row / unit pitch in floats: 444, 4 440
-constexpr size_t W43_LDS = (size_t)(G4 * UP3 + NPL * VPL4 + 64) * 4;       // 53 280 + 92 160 B + the workgroup's 64 bias values
+// Round 5: a workgroup ITEM is 32 consecutive tile rows of the layer's (unit, tile) sequence -- both MFMA row tiles full -- instead of three
+// whole units (30 of the 32 rows): 6.7 % fewer items for the same work per item.  32 tile rows start at an even tile of a unit (32 = 2 mod
+// 10) and touch at most FOUR units, so the slab has four unit slots; a slot keeps 9 of the 10 window rows (h = -1 .. 7: its tenth, the second
+// zero row below the map, is the next slot's zero row h = -1, and one spare zero row follows the last slot), which is what lets four slots
+// fit beside the V planes.  A unit that straddles two items is staged by both (input traffic x 1.25 on average; the layers sit at ~20 %
+// of the HBM rate).
+constexpr int G4 = 4, ROWS4 = VR4;               // unit slots of the slab; tile rows of an item = 32
+constexpr int HPU = HP - 1;                      // rows a slot owns
+constexpr int RP3 = WP * ROWF + 4, UP3 = HPU * RP3;                        // slab row / slot pitch in floats: 444, 3 996
+constexpr int SLABF = G4 * UP3 + RP3;            // + the spare zero row
+constexpr size_t W43_LDS = (size_t)(SLABF + NPL * VPL4 + 64) * 4;          // 65 712 + 92 160 B + the workgroup's 64 bias values
 static_assert(NPH % 3 == 0 && BX_AZI % 4 == 0 && W43_LDS <= 160 * 1024 && (RP3 * 4) % 16 == 0 && 8 * 8 * 64 * 16 <= NPL * VPL4 * 4,
               "geometry, LDS, 16-byte slab rows, output exchange inside the V planes");
 
 // ---- output transform.  nu pass and the half's partial xi sums lane-local (wino43_send), one exchange round per MFMA row tile.
 template <int NT, bool RELU>
-__device__ __forceinline__ void wino43_output(const f32x4 (&acc)[NPH][RT4], float* Vp, bool cw, int half, int wave, int lane, int ug, int units,
+__device__ __forceinline__ void wino43_output(const f32x4 (&acc)[NPH][RT4], float* Vp, bool cw, int half, int wave, int lane, int u0, int ioff, int units,
                                               int ctile, const __amdgpu_buffer_rsrc_t ors)
 {
     float4* ex = reinterpret_cast<float4*>(Vp);             // [wave][8][lane]
@@ -84,10 +95,10 @@ __device__ __forceinline__ void wino43_output(const f32x4 (&acc)[NPH][RT4], floa
         }
         __syncthreads();
         if (cw) {
-            const int R = rt * 16 + li;
+            const int R = ioff + rt * 16 + li;          // tile row inside the item's unit window
             const int g = R / NT4, t = R - g * NT4, tr = t / TC4, tc = t - tr * TC4;
-            const int u = ug * G4 + g;
-            const bool live = R < ROWS4 && u < units;
+            const int u = u0 + g;
+            const bool live = u < units;
             const int i0 = 2 * half;                        // this half's output rows of a tile: i0, i0 + 1
             const bool second_row = 4 * tr + i0 + 1 < BX_ELE;
             // raw buffer stores: ONE 32-bit offset per lane and row tile -- no 64-bit address registers held (or spilled) across the
@@ -98,7 +109,7 @@ __device__ __forceinline__ void wino43_output(const f32x4 (&acc)[NPH][RT4], floa
             // gfx950 the store then reads half-overwritten data: wino43v_kernel<6, 3, 64, 18, 2> stored wrong values for four lanes of one
             // output column (tests/test_gpu_stages.py::test_pose_conv_layer_exact[1]).  With soffset = 0 the compiler sees the hazard
             // and spaces the instructions; the group offset costs one v_add per row tile.
-            const int voff = (((g * NT) * BX_EA + (4 * tr + i0) * BX_AZI + 4 * tc) * 16 + 4 * kk) * 4 + ((ug * G4 * NT + ctile) * BX_EA * 16) * 4;
+            const int voff = (((u * NT + ctile) * BX_EA + (4 * tr + i0) * BX_AZI + 4 * tc) * 16 + 4 * kk) * 4;
             auto store = [&](int off, const f32x4 v) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, voff + off * 4, 0, 2 /* nt: streamed once */);
             };
@@ -120,14 +131,14 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
     static_assert(NLD * 2 + 1 <= NPH && (NCW == 4 || NCW == 2), "slab traffic fits the plane loop; 8 or 4 compute waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* slab = reinterpret_cast<float*>(smem);
-    float* Vp = slab + G4 * UP3;
+    float* Vp = slab + SLABF;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = wave & 1, ctl = wave >> 1;
     const bool cw = ctl < NCW;                      // compute wave (MFMAs + output); with CW = 32 waves 4..7 only stage and transform
     const int ctg = (int)blockIdx.y * NCW + (cw ? ctl : 0);
     const int li = lane & 15, kk = lane >> 4;
-    const int ngroups = (units + G4 - 1) / G4;
+    const int ngroups = (units * NT4 + ROWS4 - 1) / ROWS4;          // items of 32 tile rows
     if ((int)blockIdx.x >= ngroups) return;
 
     for (int i = tid; i < (int)(W43_LDS / 16); i += CT) reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -152,8 +163,9 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
     // read as zeros (explicit predicate: the hardware range check does not see the SGPR offset)
     const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)((long long)units * NCHUNK * NPU * 16 < 0x7fffffffLL ? (long long)units * NCHUNK * NPU * 16 : 0x7fffffffLL), 0x00020000);
     auto gload1 = [&](int q, int ug_, int cc_) {   // streamed once: non-temporal, so that the activations do not push the B fragments out of L2
-        const int soff = ((ug_ * G4 * NCHUNK + cc_) * NPU) * 16;
-        const int lim = (units - ug_ * G4) * NCHUNK * NPU;
+        const int u0_ = (ug_ * ROWS4) / NT4;       // first unit of the item's window (slot 0)
+        const int soff = ((u0_ * NCHUNK + cc_) * NPU) * 16;
+        const int lim = (units - u0_) * NCHUNK * NPU;
         const f32x4 v = (lsrc[q] >= 0 && lsrc[q] < lim) ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, lsrc[q] * 16, soff, 2 /* nt */)) : (f32x4){0.f, 0.f, 0.f, 0.f};
         st[q] = make_float4(v.x, v.y, v.z, v.w);
     };
@@ -165,15 +177,16 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
         }
     };
 
-    // ---- transform role: (tile row tR = 4 wave + lane / 16, channel slot lane % 16); the 32 lanes of the two padding rows idle
+    // ---- transform role: (tile row tR = 4 wave + lane / 16 of the item, channel slot lane % 16): all 512 threads have a tile row
     const int tR = 4 * wave + (lane >> 4);
-    const bool tact = tR < ROWS4;
-    const int tRc = tact ? tR : ROWS4 - 1;
-    const int tg = tRc / NT4, tt = tRc - tg * NT4, ttr = tt / TC4, ttc = tt - ttr * TC4;
-    const float* wsrc = slab + tg * UP3 + (4 * ttr) * RP3 + (4 * ttc) * ROWF + (lane & 15);
-    float* vdst = Vp + tRc * ROWF + (lane & 15);
+    float* vdst = Vp + tR * ROWF + (lane & 15);
+    const float* wsrc = slab;                       // window origin of this thread's tile: set per item (the unit window moves)
+    auto set_window = [&](int ioff_) {
+        const int gr = ioff_ + tR;
+        const int tg = gr / NT4, tt = gr - tg * NT4, ttr = tt / TC4, ttc = tt - ttr * TC4;
+        wsrc = slab + tg * UP3 + (4 * ttr) * RP3 + (4 * ttc) * ROWF + (lane & 15);
+    };
     auto transform = [&]() {
-        if (!tact) return;
         float t[6][6];                              // t[xi][j]: B^T d down column j
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -250,6 +263,8 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
 #pragma unroll
             for (int rt = 0; rt < RT4; ++rt) acc[p][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int ugn = ug + gstep;
+        const int u0 = (ug * ROWS4) / NT4, ioff = ug * ROWS4 - u0 * NT4;     // first unit of the item, tile offset of its first row in it
+        set_window(ioff);
 #pragma unroll 1
         for (int cc = 0; cc < NCHUNK; ++cc) {
             BX_STAMP(0);
@@ -361,7 +376,7 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
         }
         BX_STAMP(6);
         __syncthreads();             // every wave is done with the V planes: their bytes carry the exchange now
-        wino43_output<NT, RELU>(acc, Vp, cw, half, wave, lane, ug, units, ctg, ors);
+        wino43_output<NT, RELU>(acc, Vp, cw, half, wave, lane, u0, ioff, units, ctg, ors);
         BX_STAMP(7);
         ug = ugn;
         if (ug >= ngroups) break;
@@ -391,7 +406,7 @@ int launch_wino43(bx_ctx* c, int layer, hipStream_t s, const ConvLayerDev& L, co
         if (cap < 1) cap = 1;
         if (c->conv_cap_override > 0 && c->conv_cap_override < cap) cap = c->conv_cap_override;
     }
-    int grid = (units + G4 - 1) / G4;
+    int grid = (units * NT4 + ROWS4 - 1) / ROWS4;
     if (grid <= 0) return BX_OK;
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(k, dim3(grid, COUT / CW), dim3(CT), W43_LDS, s, in, units, L.Wwino43, L.b, out, c->skip,
