@@ -158,6 +158,7 @@ def main():
     ap.add_argument("--e2e-pairs", type=int, default=96, help="pairs of the file-driven end-to-end measurement per RNG mode (0 = skip; N = 1 only); 96 = the step count of the hot-path measurement it is compared with (round 4 ran 24: fill and drain of 16 pairs in flight were a third of that run)")
     ap.add_argument("--num-fps", type=int, default=5000)
     ap.add_argument("--latency-tiles", type=int, default=2, help="keypoint tiles of the latency-form measurement (0/1 = skip it)")
+    ap.add_argument("--keypoint-tiles", type=int, default=0, help="bx_params.keypoint_tiles of the MAIN contexts (0 / 1 = throughput form; >= 2 = latency form: FPS in tiles on the context's own stream, same results bit for bit)")
     ap.add_argument("--ppp", type=int, default=1024)
     ap.add_argument("--scales", type=int, default=3)
     ap.add_argument("--workload", choices=list(WORKLOADS), default="3dmatch",
@@ -169,7 +170,7 @@ def main():
     # HIP multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues: with more streams than queues two pairs share
     # a queue and run strictly one after the other (measured: 4 pairs in flight were SLOWER than 3).  One queue per pair in flight
     # (+ the null stream and the copy queue); read once when the HIP runtime initialises, i.e. before the first torch.cuda call.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(8, args.inflight + 4)))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(8, args.inflight * (3 if args.keypoint_tiles > 1 else 1) + 4)))
 
     import torch
     import torch.distributed as dist
@@ -201,6 +202,8 @@ def main():
         cfg.match.enable_early_exit = True      # config/outdoor_config.py:76 (the TIERS configs inherit it)
         cfg.match.early_exit_min_inliers = 50
     S, K, P = args.scales, args.num_fps, args.ppp
+    if args.keypoint_tiles > 1:
+        cfg.test.keypoint_tiles = args.keypoint_tiles
     # arithmetic forms: explicit configuration (bx_params), echoed by every bx_result and checked in harvest() -- never the environment
     for key, val in (("desc_conv", args.desc_conv), ("pose_conv", args.pose_conv), ("cost_l0", args.cost_l0)):
         if val:
