@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void patch_axis_kernel(const float* __restrict
     const float* pp = patches + (size_t)q * P * 3;
     const float* cp = cnt ? kpts + (size_t)q * 3 : pp + (size_t)(P - 1) * 3;
     const float cx = cp[0], cy = cp[1], cz = cp[2];
-    const int Pe = cnt ? cnt[q] : P;
+    const int Pe = cnt ? min(max(cnt[q], 1), P - 1) : P;      // counts come from device memory through a public entry: clamped to their documented range
     float c00 = 0.f, c01 = 0.f, c02 = 0.f, c11 = 0.f, c12 = 0.f, c22 = 0.f;
     for (int i = lane; i < Pe; i += 64) {
         const float dx = pp[(size_t)i * 3] - cx, dy = pp[(size_t)i * 3 + 1] - cy, dz = pp[(size_t)i * 3 + 2] - cz;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(PF_THREADS) void patch_features_kernel(
     // slot contributes (utils/common.py:440-447: padded slots are zeroed) -- and ReLU + max do not see the sign of a zero.  The
     // features are bit-identical to those of the padded patch (tests/test_gpu_counted.py), the row lists hold real points only
     // (no more overflowing inner-shell lists at the small scales) and the sweep below runs over Pe instead of P points.
-    const int Pe = cnt ? __builtin_amdgcn_readfirstlane(cnt[q]) : P;
+    const int Pe = cnt ? min(max(__builtin_amdgcn_readfirstlane(cnt[q]), 1), P - 1) : P;    // clamped: an out-of-range count must not index LDS
     const float* cp = cnt ? kpts + (size_t)q * 3 : pp + (size_t)(P - 1) * 3;
     const float cx = cp[0], cy = cp[1], cz = cp[2];
     float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};

@@ -398,6 +398,9 @@ int launch_wino43(bx_ctx* c, int layer, hipStream_t s, const ConvLayerDev& L, co
         bx_set_error("winograd F(4x4) layer %d: geometry mismatch (%d chunks, %d channels)", layer, L.nchunk, L.cout);
         return BX_ERR_STATE;
     }
+    // the kernel addresses its input and output through raw buffer resources with 32-bit byte offsets: a map set of 2 GiB or more
+    // (~30 k units on the 128-channel layers) is "not served" -- the direct kernels (64-bit addressing) take it
+    if (!w43::fits_i32((long long)units * NCHUNK * BX_EA * 64) || !w43::fits_i32((long long)units * (COUT / 16) * BX_EA * 64)) return -1;
     auto k = wino43_kernel<NCHUNK, COUT, CW, RELU>;
     int& cap = c->wino_cap[layer];
     if (cap == 0) {

@@ -240,6 +240,9 @@ int launch_wino43v(bx_ctx* c, int layer, hipStream_t s, const ConvLayerDev& L, c
         bx_set_error("winograd F(4x4) CostNet layer %d: geometry mismatch (%d chunks, %d taps, %d channels)", layer, L.nchunk, L.ntaps, L.cout);
         return BX_ERR_STATE;
     }
+    // 32-bit byte offsets inside the kernel (raw buffer resources): 2 GiB or more of input or output maps (~17 k matches on layer 1) is
+    // "not served" -- the direct kernels (64-bit addressing) take the layer
+    if (!w43::fits_i32((long long)max_units * GE::NCH * GE::PIN3 * 64) || !w43::fits_i32((long long)max_units * (COUT / 16) * (GE::DO * GE::DO) * 64)) return -1;
     auto k = wino43v_kernel<NE, FOLD, COUT, D, G, RELU>;
     int& cap = c->wino43v_cap[layer];
     if (cap == 0) {

@@ -11,6 +11,9 @@ constexpr int ROWF = 20;                         // floats per LDS row (16 + 4 p
 constexpr int RT4 = 2, VR4 = RT4 * 16, VPL4 = VR4 * ROWF;   // two MFMA row tiles = 32 tile rows per workgroup item
 constexpr int NPL = 36, NPH = 18;                // planes, planes per wave half
 constexpr int CT = 512;
+// the F(4x4) kernels address maps with 32-bit byte offsets (lane offset + SGPR group offset, num_records clamped to 2^31 - 1): the
+// launchers refuse -- return -1, "not served" -- anything that does not fit, with a margin for the largest in-item offset
+inline bool fits_i32(long long bytes) { return bytes < 0x7fffffffLL - (1LL << 24); }
 
 // ---- packed f32 (round 5).  The vector ALU and the f32 MFMA are ONE resource on this chip (profiles/r05_mfma_coissue.txt: a VALU
 // instruction costs its 4-5 issue cycles whichever wave issues it), so what the transforms cost is their instruction count, and a

@@ -215,7 +215,8 @@ int bx_ball_group(bx_ctx *ctx, void *stream, const float *pts_perm, int32_t n, c
  * copies of the keypoint -- the padded slots (group_idx == group_idx[:, :, 0]) and slot P - 1 of models/patch_embedder.py:105-111
  * -- so bx_ball_group_counted writes only the first count_out[k] = clamp(hits, 1, P - 1) slots of patches_out [K][P][3] (the rest
  * of a row is left untouched) and bx_patch_features_counted takes (patches, counts, kpts) and produces R_out / feat_out
- * bit-identical to bx_patch_features on the padded patch (tests/test_gpu_counted.py).                                          */
+ * bit-identical to bx_patch_features on the padded patch (tests/test_gpu_counted.py).  counts[k] must lie in [1, P - 1]; values
+ * outside that range are clamped into it by the kernels (never trusted as an index).                                            */
 int bx_ball_group_counted(bx_ctx *ctx, void *stream, const float *pts_perm, int32_t n, const float *kpts, int32_t K,
                           const double *radius, int32_t P, float *patches_out, int32_t *count_out);
 int bx_patch_features_counted(bx_ctx *ctx, void *stream, const float *patches, const int32_t *counts, const float *kpts,

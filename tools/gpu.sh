@@ -10,7 +10,7 @@
 #   bench[:TAG[,args...]]   python bench.py <args with ',' -> ' '>  -> bench_TAG.json (+ one summary line)
 #   layers[:TAG[,SO]]       tools/bench_conv_layers.py (Desc stack per layer); SO = variants/libbufferx_X.so built by tools/build_variant.sh
 #   stage:WHAT[,args...]    tools/bench_stage.py WHAT (ball | patch | conv | all)
-#   ubench:NAME             hipcc tools/ubench/NAME.hip && run it -> ubench_NAME.txt
+#   ubench:NAME[,args...]   hipcc tools/ubench/NAME.hip && run it (with args) -> ubench_NAME.txt
 #   profile[:TAG]           rocprofv3 kernel-trace + the PMC passes of the bench command -> prof_TAG/ (summaries for profiles/)
 #   kstat:TAG,cmd...        rocprofv3 --kernel-trace --stats of `python <cmd with ',' -> ' '>` -> per-kernel table (top 25)
 #   env:VAR=VALUE           export VAR for the following steps (e.g. env:BX_HIP_SO=...)
@@ -57,9 +57,10 @@ for step in "$@"; do
       timeout 900 python tools/bench_stage.py $w $rest 2>&1 | tail -12 | tee -a $OUT/stage_$w.jsonl;;
     ubench)
       # a binary cross-compiled in the build container (git-ignored, travels with the snapshot) saves GPU-box minutes
-      if [ -x tools/ubench/$arg ] && [ tools/ubench/$arg -nt tools/ubench/$arg.hip ]; then UB=tools/ubench/$arg
-      else UB=/tmp/ub_$arg; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -o $UB tools/ubench/$arg.hip 2>&1 | tail -3; fi
-      timeout 600 $UB 2>&1 | tee $OUT/ubench_$arg.txt | tail -120;;
+      ub=${arg%%,*}; rest=""; [[ "$arg" == *,* ]] && rest=$(echo "${arg#*,}" | tr ',' ' ')
+      if [ -x tools/ubench/$ub ] && [ tools/ubench/$ub -nt tools/ubench/$ub.hip ]; then UB=tools/ubench/$ub
+      else UB=/tmp/ub_$ub; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -o $UB tools/ubench/$ub.hip 2>&1 | tail -3; fi
+      timeout 600 $UB $rest 2>&1 | tee $OUT/ubench_$ub.txt | tail -120;;
     profile)
       TAG=${arg:-r05}; P=$OUT/prof_$TAG; rm -rf $P; mkdir -p $P
       CMD="python bench.py --steps 4 --warmup 1 --inflight 1 --no-cpu-baseline --latency-tiles 0 --e2e-pairs 0"
