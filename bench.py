@@ -122,23 +122,21 @@ def make_inputs(bx, n_pairs, base_seed, S, workload):
 
 
 def spawn_ranks(n):
-    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU, LOCAL_RANK = GPU index) with the
-    torch.distributed environment of a single-node job, pass rank 0's JSON line through."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = rc or p.wait()
-    sys.stdout.write(out.decode())
+    """`python bench.py --gpus N` without a launcher: N ranks of this script through buffer-x_amd/dist.py::spawn_ranks (fail-fast:
+    the first rank that dies ends the job with its stderr tail and a non-zero exit code instead of leaving the others in the
+    collective until its timeout; per-rank logs kept), rank 0's JSON line passed through."""
+    import bufferx_amd  # noqa: F401  (registers the hyphenated package directory)
+    from bufferx_amd import dist as D
+    rc, out0, log_dir = D.spawn_ranks(n, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      log_dir=os.environ.get("BX_RANK_LOG_DIR"))
+    sys.stdout.write(out0)
     sys.stdout.flush()
+    if rc == 0:
+        # rank 0's stderr carries the progress notes of the run: pass them on like a single-process run would
+        try:
+            sys.stderr.write(open(os.path.join(log_dir, "rank0.err")).read())
+        except OSError:
+            pass
     sys.exit(rc)
 
 
@@ -186,11 +184,21 @@ def main():
     if os.environ.get("BX_BENCH_SAME_GPU"):
         local = 0
     torch.cuda.set_device(local)
+    affinity = None
     if world > 1:
+        # one process per GPU: host threads next to the GPU (NUMA node from sysfs, else an even split of the CPUs); N = 1 is untouched
+        try:
+            pr = torch.cuda.get_device_properties(local)
+            pci = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pci = None
+        affinity = D.bind_rank_to_gpu(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), pci)
+        import datetime
+        tmo = datetime.timedelta(seconds=float(os.environ.get("BX_DIST_TIMEOUT_S", "180")))     # a rank that never arrives is an error, not a hang
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"), timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
     dev = f"cuda:{local}"
     coll_dev = dev if backend == "nccl" else None      # RCCL collectives take device tensors, gloo host tensors
 
@@ -295,6 +303,10 @@ def main():
     rank_rows = D.gather_rows(np.array([[rank, dt_local, local, torch.cuda.current_device()]], np.float64), world, device=coll_dev)
 
     assert len(allrec) == args.steps * world
+    # the job the driver asked for is the job that ran: every rank arrived in the collective, every pair id is there exactly once
+    assert len(rank_rows) == args.gpus and sorted(int(r[0]) for r in rank_rows) == list(range(args.gpus)), \
+        "--gpus %d but the all-gather saw ranks %s" % (args.gpus, [int(r[0]) for r in rank_rows])
+    assert np.array_equal(np.sort(allrec[:, 0].astype(np.int64)), np.arange(args.steps * world)), "pair ids missing from the gathered records"
     if rank == 0 and args.dump_records:
         np.save(args.dump_records, allrec)
     # Latency at ONE pair in flight (service time of a pair; p50_ms_per_pair above is queueing latency at `inflight` pairs in flight)
@@ -480,7 +492,8 @@ def main():
                        "weights": "seeded random (reference snapshot layout)", "mean_points_per_cloud": nmean,
                        "workload_generator": "synth.make_pair v2 (round 2+: shared=True noise-free partial-overlap fragments; round 1 used "
                                              "independently sampled jittered fragments = --workload 3dmatch-noisy; rates of the two are not comparable)"},
-            "collective": collective_evidence(allrec, rank_rows, world, backend if world > 1 else "none (world 1)", args.steps),
+            "collective": dict(collective_evidence(allrec, rank_rows, world, backend if world > 1 else "none (world 1)", args.steps),
+                               **({"rank0_cpu_affinity": affinity} if affinity else {})),
             "host_ms_per_pair": round(host_ms_per_pair, 3),
             "host_note": "CPU time of one rank per pair inside the timed region: enqueueing the launches of bx_register_pair + packing the "
                          "result record (stream waits excluded); a rank is host-bound only when this approaches ms_per_step",

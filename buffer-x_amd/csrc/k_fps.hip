@@ -36,6 +36,9 @@
 //     re-publishes its cached winner.  Buckets are dealt round-robin to the workgroups and waves of a cloud (bucket b -> workgroup
 //     b % G, wave b / G), so that the few buckets near a new sample sit on different SIMDs.
 #include "bx_common.h"
+// The bucket pruning is exact only because the box distance and the point distances are the SAME unfused operation sequences (monotone
+// rounding): no implicit FMA contraction in this file, whatever flags a variant build passes (csrc/Makefile sets -ffp-contract=off too).
+#pragma clang fp contract(off)
 
 namespace {
 
@@ -239,7 +242,9 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
     lox = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(lox))); loy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(loy)));
     loz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(loz))); hix = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hix)));
     hiy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hiy))); hiz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(hiz)));
-    float wmax = 3.0e38f;                          // the bucket's largest running min-distance: unknown -> the first iteration scans
+    float wmax = 0.0f;                             // the bucket's largest running min-distance, known from the first scan on
+    bool scanned = false;                          // (an explicit flag, not a 3e38 sentinel: a box distance that overflows to inf / NaN on
+                                                   //  far-out coordinates must not keep a bucket from ever being scanned)
     long long wk_c = (long long)0x8000000000000000LL;   // cached winner of the bucket {key, local slot | coordinates}
     int ws_c = 0;
     float wx_c = 0.f, wy_c = 0.f, wz_c = 0.f;
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
         if (a.prune) {
             const float ex = fmaxf(fmaxf(lox - cx, cx - hix), 0.0f), ey = fmaxf(fmaxf(loy - cy, cy - hiy), 0.0f), ez = fmaxf(fmaxf(loz - cz, cz - hiz), 0.0f);
             const float db = (ex * ex + ey * ey) + ez * ez;
-            scan = __builtin_amdgcn_readfirstlane(db < wmax ? 1 : 0) != 0;
+            scan = !scanned || __builtin_amdgcn_readfirstlane(db < wmax ? 1 : 0) != 0;
         }
         if (scan) {
             float bd = -1.0f, bx = 0.f, by = 0.f, bz = 0.f;
@@ -341,6 +346,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
             // keys are unique per thread (they embed the point index): the winner's lane broadcasts its slot / coordinates
             const int wl = __ffsll((long long)__ballot(key == wk)) - 1;
             wk_c = wk;
+            scanned = true;
             wmax = __int_as_float((int)(wk >> 32));            // the bucket's largest min-distance (-1: no candidate left)
             if (LDSXYZ) {
                 ws_c = __builtin_amdgcn_readlane(bi * FPS_THREADS + t, wl);

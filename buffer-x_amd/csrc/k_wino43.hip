@@ -21,10 +21,12 @@
 //    (vmcnt), so the pieces of the next chunk are requested right after the chunk's first barrier -- a transform and a whole MFMA phase
 //    before they are needed, never between two ring loads -- and written to the slab all at once behind the last plane (the write's
 //    wait for its piece is a wait for every load in flight: one such drain per chunk, under the tail of the MFMAs).
-//  * transform (round 5): lane (tile row, channel PAIR) of a wave that owns three xi rows: 30 ds_read_b64, 72 v_pk_*_f32 (both passes
-//    on two channels at once, the pairs come for free from the 8-byte reads), 18 ds_write_b64 into the V planes.  Round 4: one channel
-//    per lane, 36 dword reads, 144 + 19 VALU, 36 ds_write_b32 (round 3 re-read the window once per xi: 253 KB of slab reads per chunk
-//    instead of 69 KB).  Slab row pitch 22 x 20 + 4 floats.
+//  * transform: lane (tile row tR = 4 wave + lane / 16 of the item, channel slot lane % 16) -- every one of the 512 threads owns one
+//    (tile row, channel) of the chunk: 36 ds_read_b32 of its 6 x 6 window from the slab (row pitch 22 x 20 + 4 floats), B^T d down
+//    the six columns and along the six rows on scalar f32 (bt6s: 144 + 19 VALU), 36 ds_write_b32 into the V planes (round 3 re-read
+//    the window once per xi: 253 KB of slab reads per chunk instead of 69 KB).  A channel-PAIR form (ds_read_b64, 72 v_pk_*_f32,
+//    ds_write_b64, three xi rows per wave) was built in round 5, is bit-exact and measured 2.6 % slower
+//    (profiles/r05_wino43_variants.txt): it is NOT in the library; its helpers were removed from wino43_common.h in round 6.
 //  * MFMA phase: SWAPPED operands (A = weight fragment, B = V rows), so accumulator register r of lane (li, kk) is
 //    M[tile row rt * 16 + li][slot 4 kk + r]: a lane owns four contiguous output slots of one tile.  B fragments in a ring of three
 //    planes through raw buffer loads (descriptor + wave-uniform offset in SGPRs: no VALU address arithmetic between the MFMAs).
@@ -35,9 +37,7 @@
 //    register pairs (r, r + 1) of the MFMA results (no shuffles: wino43_common.h), a half keeps only the two sums its own rows need
 //    across the exchange, the stores are raw buffer stores (32-bit lane offset + SGPR group offset), the slab pieces raw buffer loads,
 //    and the phase's lane constants + the bias (LDS) are re-derived per group instead of living -- spilled -- across the MFMA pipeline:
-//    2 spilled VGPRs instead of 8-10, stack -1.3 % (profiles/r05_wino43_variants.txt).  A channel-pair packed INPUT transform
-//    (ds_read_b64 / 72 v_pk / ds_write_b64 per lane: fewer LDS cycles AND fewer VALU instructions on paper) was built, is bit-exact and
-//    measured 2.6 % SLOWER; it is not in the library.
+//    2 spilled VGPRs instead of 8-10, stack -1.3 % (profiles/r05_wino43_variants.txt).
 // Measured and NOT kept: the window straight from global memory (36 dword loads per thread: the texture addresser needs ~16 cycles per
 // wave-instruction of four 64-byte segments -- 1 800-4 700 cycles of blocked issue per chunk), a start stagger of the workgroups (no
 // change: the output phase is not a chip-wide burst), temporal output stores (no change).

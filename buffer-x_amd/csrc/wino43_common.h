@@ -18,9 +18,9 @@ inline bool fits_i32(long long bytes) { return bytes < 0x7fffffffLL - (1LL << 24
 // ---- packed f32 (round 5).  The vector ALU and the f32 MFMA are ONE resource on this chip (profiles/r05_mfma_coissue.txt: a VALU
 // instruction costs its 4-5 issue cycles whichever wave issues it), so what the transforms cost is their instruction count, and a
 // v_pk_*_f32 does two lanes' worth for the price of one -- but only when its operands already sit in aligned register pairs (hipcc's own
-// SLP packing paid for the pairs with v_mov and gained nothing).  Both transforms are written on explicit two-element vectors whose pairs
-// are free: two CHANNELS read as one ds_read_b64 (input transform), two accumulator registers r, r + 1 of one MFMA result (output
-// transform).  Element by element the expressions are those of the contract (oracle/bx_oracle.c::bxo_conv_wino43); a - b is written
+// SLP packing paid for the pairs with v_mov and gained nothing).  The OUTPUT transform is written on explicit two-element vectors whose
+// pairs are free: two accumulator registers r, r + 1 of one MFMA result.  (The input transform stays scalar: its channel-pair form
+// measured slower, profiles/r05_wino43_variants.txt.)  Element by element the expressions are those of the contract (oracle/bx_oracle.c::bxo_conv_wino43); a - b is written
 // fma(-1, b, a) -- the same single rounding, signed zeros included -- because hipcc scalarises a packed subtraction.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 pk2(float k) { return (f32x2){k, k}; }
@@ -31,29 +31,7 @@ __device__ __forceinline__ f32x2 hi2(const f32x4 v) { return __builtin_shuffleve
 __device__ __forceinline__ f32x4 cat2(const f32x2 a, const f32x2 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3); }
 
 // the six results of B^T on a 6-vector (contract: bxo_conv_wino43; t3 / t4 as fmaf(+-2, d3 - d1, c): 2 x is exact, so the rounding is
-// that of c +- e), on two channels at once; the halves (results 0..2 / 3..5) share nothing, so a thread that owns three xi rows of the
-// column pass computes only its half
-__device__ __forceinline__ void bt6p_lo(f32x2 d0, f32x2 d1, f32x2 d2, f32x2 d3, f32x2 d4, f32x2& o0, f32x2& o1, f32x2& o2)
-{
-    o0 = pfma(4.0f, d0, pfma(-5.0f, d2, d4));
-    const f32x2 a = pfma(-4.0f, d2, d4), b = pfma(-4.0f, d1, d3);
-    o1 = a + b;
-    o2 = psub(a, b);
-}
-__device__ __forceinline__ void bt6p_hi(f32x2 d1, f32x2 d2, f32x2 d3, f32x2 d4, f32x2 d5, f32x2& o3, f32x2& o4, f32x2& o5)
-{
-    const f32x2 c = psub(d4, d2), s = psub(d3, d1);
-    o3 = pfma(2.0f, s, c);
-    o4 = pfma(-2.0f, s, c);
-    o5 = pfma(4.0f, d1, pfma(-5.0f, d3, d5));
-}
-__device__ __forceinline__ void bt6p(f32x2 d0, f32x2 d1, f32x2 d2, f32x2 d3, f32x2 d4, f32x2 d5, f32x2 (&o)[6])
-{
-    bt6p_lo(d0, d1, d2, d3, d4, o[0], o[1], o[2]);
-    bt6p_hi(d1, d2, d3, d4, d5, o[3], o[4], o[5]);
-}
-
-// scalar form (the valid-map kernel's edge handling still uses it)
+// that of c +- e): the INPUT transform of both kernels, scalar f32
 __device__ __forceinline__ void bt6s(float d0, float d1, float d2, float d3, float d4, float d5, float (&o)[6])
 {
     o[0] = fmaf(4.0f, d0, fmaf(-5.0f, d2, d4));

@@ -62,17 +62,32 @@ def report(name, ins, spills):
         runs.append(cur)
         longest = max(runs, key=len)
         drains = sum(1 for l in ins[longest[0]:longest[-1]] if re.match(r"s_waitcnt\s+vmcnt\(0\)", l))
-    # round 5: a VALU write to the data registers of a 16-byte store in the very next issue slot.  hipcc leaves no wait state there when the
+    # round 5 (two slots since round 6): a VALU write to the data registers of a 16-byte store within the next two wait states.  hipcc leaves no wait state there when the
     # store carries an SGPR offset, and gfx950 then stores half-overwritten data (k_wino43.hip::wino43_output): must be 0
     hazard = 0
     for i, l in enumerate(ins[:-1]):
         m = re.match(r"(?:buffer|global)_store_dwordx[34] (?:v\d+, |v\[\d+:\d+\], )?v\[(\d+):(\d+)\]", l) or re.match(r"buffer_store_dwordx[34] v\[(\d+):(\d+)\]", l)
-        w = re.match(r"v_\w+ v\[?(\d+)(?::(\d+))?\]?", ins[i + 1])
-        if m and w:
-            a, b, lo = int(m.group(1)), int(m.group(2)), int(w.group(1))
-            hi = int(w.group(2) or lo)
-            if not (hi < a or lo > b):
-                hazard += 1
+        if not m:
+            continue
+        a, b = int(m.group(1)), int(m.group(2))
+        # LLVM's rule for the gfx940 family: TWO wait states between a > 64-bit store and a VALU write of its data registers.  Walk the
+        # issue slots behind the store: an `s_nop N` is N + 1 states, any other instruction one; a VALU write inside the first two is a hazard.
+        states, j = 0, i + 1
+        while j < len(ins) and states < 2:
+            nxt = ins[j]
+            nop = re.match(r"s_nop (\d+)", nxt)
+            if nop:
+                states += int(nop.group(1)) + 1
+            else:
+                w = re.match(r"v_\w+ v\[?(\d+)(?::(\d+))?\]?", nxt)
+                if w:
+                    lo = int(w.group(1))
+                    hi = int(w.group(2) or lo)
+                    if not (hi < a or lo > b):
+                        hazard += 1
+                        break
+                states += 1
+            j += 1
     valu = sum(1 for l in ins if l.startswith("v_") and not l.startswith("v_mfma"))
     scr_loop = 0
     if mf:
