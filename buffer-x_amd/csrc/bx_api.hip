@@ -392,6 +392,8 @@ static int create_impl(bx_ctx* c, int device_id)
         c->conv_persist = (!e || atoi(e) != 0) ? 1 : 0;
         e = getenv("BX_CONV_PERSIST_CAP");
         c->conv_cap_override = e ? atoi(e) : 0;
+        e = getenv("BX_RAD_SLICES");                 // measurement hook (k_radius.hip); results do not depend on it
+        c->rad_slices = e ? atoi(e) : 0;
         // arithmetic forms: bx_params (validated by bx_create), never the environment
         c->use_wino = p.desc_conv_form == BX_DESC_CONV_DIRECT ? 0 : (p.desc_conv_form == BX_DESC_CONV_WINOGRAD22 ? 1 : 2);
         c->use_wino_pose = p.pose_conv_form == BX_POSE_CONV_DIRECT ? 0 : (p.pose_conv_form == BX_POSE_CONV_WINOGRAD22 ? 1 : 2);

@@ -22,13 +22,19 @@ __device__ __forceinline__ float thr_of(int m)
     return (float)(r * r);
 }
 
-__global__ __launch_bounds__(256) void radius_hist_kernel(const float* __restrict__ pts, int n_pts,
+// Round 6: 1024-thread workgroups (RH_T) share one LDS histogram: the 33 KB that capped a CU at four 256-thread workgroups (16 waves)
+// now carry two 1024-thread ones (32 waves: the per-distance bin search is latency-bound, occupancy is what it wants) and the global flush
+// -- 8194 64-bit atomics per workgroup -- happens 512 instead of 2048 times per launch; and the bin search starts at floor(t) + 1, where
+// the answer almost always is (d2 < thr[m] <=> t < m up to the rounding of thr), so the common case costs two threshold evaluations
+// instead of three.  The two correcting loops are unchanged: the bin is exact from any start.
+constexpr int RH_T = 1024;
+__global__ __launch_bounds__(RH_T) void radius_hist_kernel(const float* __restrict__ pts, int n_pts,
                                                           const float* __restrict__ kpts, int nk,
                                                           const float* __restrict__ thr, unsigned long long* hist)
 {
     __shared__ unsigned h[NB];
     __shared__ float sk[64][4];
-    for (int i = threadIdx.x; i < NB; i += 256) h[i] = 0;
+    for (int i = threadIdx.x; i < NB; i += RH_T) h[i] = 0;
     const int k0 = blockIdx.y * 64;
     const int kc = min(64, nk - k0);
     if (threadIdx.x < 64) {
@@ -39,14 +45,14 @@ __global__ __launch_bounds__(256) void radius_hist_kernel(const float* __restric
         sk[q][3] = (kx * kx + ky * ky) + kz * kz;
     }
     __syncthreads();
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < n_pts; j += gridDim.x * 256) {
+    for (int j = blockIdx.x * RH_T + threadIdx.x; j < n_pts; j += gridDim.x * RH_T) {
         float px = pts[(size_t)j * 3], py = pts[(size_t)j * 3 + 1], pz = pts[(size_t)j * 3 + 2];
         float y2 = (px * px + py * py) + pz * pz;
         for (int q = 0; q < kc; ++q) {
             float xy = (sk[q][0] * px + sk[q][1] * py) + sk[q][2] * pz;
             float d2 = (sk[q][3] + y2) - 2.0f * xy;
             if (!(d2 <= 25.0f)) continue;  // dists_sqr[dists_sqr <= max_r*max_r]
-            int m = (int)(sqrtf(fmaxf(d2, 0.0f)) * 1638.4f);
+            int m = (int)(sqrtf(fmaxf(d2, 0.0f)) * 1638.4f) + 1;
             m = m < 0 ? 0 : (m > 8192 ? 8192 : m);
             while (m <= 8192 && !(d2 < thr_of(m))) ++m;
             while (m > 0 && d2 < thr_of(m - 1)) --m;
@@ -54,7 +60,7 @@ __global__ __launch_bounds__(256) void radius_hist_kernel(const float* __restric
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < NB; i += 256)
+    for (int i = threadIdx.x; i < NB; i += RH_T)
         if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
 }
 
@@ -112,14 +118,16 @@ int bxk_radius_hist(bx_ctx* c, hipStream_t s, const float* pts, int n_pts, const
 {
     BX_HIP(hipMemsetAsync(c->rad_hist, 0, sizeof(unsigned long long) * NB, s));
     if (n_pts <= 0 || nk <= 0) return BX_OK;
-    // every workgroup ends with a flush of its 8194-bin LDS histogram into the global one (64-bit atomics: 16 M of them = 102 MB of
-    // write traffic per launch for a 64 KB result).  Measured in round 3: cutting the flushes eightfold (8 point slices instead of 64)
-    // DOUBLES the kernel time (317 -> 629 us) -- 4 waves per CU cannot cover the latency of the per-distance bin search; the flush
-    // traffic is not what the kernel waits for, occupancy is.  64 slices stay.
-    int gx = (n_pts + 255) / 256;
-    if (gx > 64) gx = 64;
+    // every workgroup ends with a flush of its 8194-bin LDS histogram into the global one (64-bit atomics; rounds 1-5: 2048 workgroups
+    // of 256 threads = 16 M atomics = 102 MB of write traffic per launch for a 64 KB result).  Measured in round 3: cutting the flushes
+    // eightfold by cutting the point slices (8 instead of 64) DOUBLES the kernel time (317 -> 629 us) -- 4 waves per CU cannot cover the
+    // latency of the per-distance bin search; occupancy is what the kernel wants.  Round 6 cuts the flushes fourfold the other way:
+    // 16 slices of 1024-thread workgroups (see RH_T): twice the waves per CU, a quarter of the flush traffic.
+    int gx = (n_pts + RH_T - 1) / RH_T;
+    const int gmax = c->rad_slices > 0 ? c->rad_slices : 16;
+    if (gx > gmax) gx = gmax;
     dim3 grid(gx, (nk + 63) / 64);
-    hipLaunchKernelGGL(radius_hist_kernel, grid, dim3(256), 0, s, pts, n_pts, kpts, nk, c->d_rad_thr, c->rad_hist);
+    hipLaunchKernelGGL(radius_hist_kernel, grid, dim3(RH_T), 0, s, pts, n_pts, kpts, nk, c->d_rad_thr, c->rad_hist);
     BX_LAUNCH_CHECK();
     return BX_OK;
 }

@@ -34,7 +34,7 @@ def timeit(torch, fn, iters, warm=3):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["ball", "patch", "conv", "all"])
+    ap.add_argument("what", choices=["ball", "patch", "conv", "radius", "all"])
     ap.add_argument("--n", type=int, default=30000)
     ap.add_argument("--K", type=int, default=5000)
     ap.add_argument("--P", type=int, default=1024)
@@ -62,6 +62,11 @@ def main():
     torch.cuda.synchronize()
     rr = radii.cpu().numpy()
     out = []
+    if args.what in ("radius", "all"):
+        kp2 = kp[:2000].contiguous()
+        us = timeit(torch, lambda: ctx.radius(dpts, n, kp2, [5, 2, 0.5]), args.iters)
+        out.append(dict(stage="radius (memset + radius_hist_kernel + radius_bisect_kernel)", n=n, nk=2000, us=round(us, 1), slices=os.environ.get("BX_RAD_SLICES", "default"),
+                        Gdist_per_s=round(2000.0 * n / us / 1e3, 1), radii=[float(v) for v in rr]))
     if args.what in ("ball", "all"):
         for si in range(3):
             rad = radii[si:si + 1].contiguous()
