@@ -150,7 +150,7 @@ void carve(bx_ctx* c, char* base, size_t* total)
     c->inlier_ind = cv.take<int32_t>(SK);
     c->rad_hist = cv.take<unsigned long long>(8200);
     c->fps_dist = nullptr;
-    c->fps_slots = cv.take<unsigned long long>(2 * 2 * 64 * 8);      // k_fps.hip: [cloud][parity][FPS_MAX_G][FPS_REC]
+    c->fps_slots = cv.take<unsigned long long>(2 * 2 * 64 * 64);     // k_fps.hip: [cloud][parity][FPS_MAX_G][FPS_REC = 64]
     c->fps_hello = cv.take<unsigned long long>(2 * 64);
     c->fps_ord = cv.take<int32_t>(2 * NMAX);
     c->fps_cell = cv.take<unsigned short>(2 * NMAX);

@@ -45,7 +45,11 @@ namespace {
 constexpr int FPS_THREADS = 1024;
 constexpr int FPS_WAVES = FPS_THREADS / 64;
 constexpr int FPS_MAX_G = 64;            // 64 workgroups x 16 384 points = 1 048 576 points per cloud (the neighbour bitmap's limit too)
-constexpr int FPS_REC = 8;               // 8-byte words per exchange record: five {epoch, value} granules in one 64-byte line
+constexpr int FPS_REC = 64;              // 8-byte words per exchange record: the bound's two {epoch, value} granules, then K x five {key hi, key lo, x, y, z}
+constexpr int FPS_K = 12;                // most candidates a workgroup publishes per round (2 + 5 K <= FPS_REC; fewer when G x K would exceed the resolving wave's 64 lanes)
+constexpr int FPS_TMAX = 8;              // samples one round may resolve
+constexpr int FPS_NE = 2 * FPS_WAVES;    // entries of a workgroup: the two largest keys of each of its 16 buckets
+constexpr long long FPS_IDK = (long long)0x8000000000000000LL;    // identity of the key maximum
 constexpr int FPS_MAX_CLOUDS = 2;
 constexpr unsigned FPS_SPIN_LIMIT = 1u << 24;
 
@@ -64,10 +68,11 @@ struct FpsArgs {
     int colocate;               // 1: grid = 8 x max G, the workgroups of cloud c are the blocks with blockIdx % 8 == xcd[c]
     int xcd[FPS_MAX_CLOUDS];
     unsigned long long* hello;  // [cloud][FPS_MAX_G] placement handshake granules, zeroed in front of every launch
-    long long* dbg;             // BX_FPS_TRACE: cycle stamps of iterations 1000..1007 of workgroup 0 ([8][8])
+    long long* dbg;             // BX_FPS_TRACE: cycle stamps of rounds 100..107 of workgroup 0 ([8][8])
     int32_t* err_flag;
     const int32_t* ord[FPS_MAX_CLOUDS];   // [n] point index at every position of the Morton-cell order (bxk_fps_order)
     int prune;                  // 1: skip the buckets a new sample cannot change
+    int kmax;                   // candidates a workgroup publishes per round (<= FPS_K)
 };
 
 struct Rec {
@@ -171,11 +176,12 @@ __device__ __forceinline__ unsigned long long granule_load(unsigned long long* p
 template <int PPT>
 __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
 {
-    __shared__ long long s_key[2][FPS_WAVES];
-    __shared__ float s_xyz[2][FPS_WAVES][3];
-    __shared__ long long s_fkey[2];
-    __shared__ float s_fxyz[2][3];
-    __shared__ int s_slot[2][FPS_WAVES];           // local slot (i * 1024 + t) of every wave's winner: its coordinates sit in s_pts
+    __shared__ long long s_ekey[2][FPS_NE];        // [parity][{0: largest, 1: second largest key of the bucket}][wave]
+    __shared__ int s_eslot[2][FPS_WAVES];          // local slot (i * 1024 + t) of every bucket's largest: its coordinates sit in s_pts (PPT <= 8)
+    __shared__ float s_exyz[2][FPS_WAVES][3];      // or its coordinates (PPT 16)
+    __shared__ float4 s_pick[2][FPS_TMAX];         // the samples a round resolved (x, y, z), applied by every wave in the next round
+    __shared__ long long s_pkey[2][FPS_TMAX];      // and their keys (the point index is the low word)
+    __shared__ int s_npick[2];
 
     int cloud = 0, g;
     if (a.colocate) {
@@ -207,25 +213,39 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
     constexpr bool LDSXYZ = PPT <= 8;
     constexpr int NP = PPT * FPS_THREADS;
     extern __shared__ float s_pts[];
-    float px[PPT], py[PPT], pz[PPT], td[PPT];
-    unsigned pt[PPT];                              // low word of the point's key = ~tie-break(k): the tie rule, and k itself (invertible)
+    // running min-distances: registers (PPT <= 8) or, for PPT 16 -- whose coordinates alone take 48 of the 128 VGPRs a 1024-thread
+    // workgroup leaves a lane --, the dynamic LDS ([16][1024] floats, conflict-free: consecutive lanes, consecutive words)
+    constexpr bool LDSTD = !LDSXYZ;
+    float px[PPT], py[PPT], pz[PPT], td_r[LDSTD ? 1 : PPT];
+#define TD(i) (*(LDSTD ? &s_pts[(i) * FPS_THREADS + t] : &td_r[LDSTD ? 0 : (i)]))
+    // low word of the point's key = ~tie-break(k): the tie rule, and k itself (invertible).  PPT 16 has no register for it (the kernel
+    // sits at its 128-VGPR ceiling): the word is re-derived from the spatial order where a bucket's entries are computed / its state saved
+    constexpr int NPT = LDSXYZ ? PPT : 1;
+    unsigned pt[NPT];
+    auto tiebreak = [&](int i) -> unsigned {
+        const int sp = sp0 + i * 64;
+        if (sp >= n) return 0u;
+        const int k = ord ? ord[sp] : sp;
+        return ~((((unsigned)k & tmask) << 23) | ((unsigned)k >> lt));
+    };
     float lox = 3.0e38f, loy = 3.0e38f, loz = 3.0e38f, hix = -3.0e38f, hiy = -3.0e38f, hiz = -3.0e38f;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
         const int sp = sp0 + i * 64;
         if (sp < n) {
             const int k = ord ? ord[sp] : sp;
-            pt[i] = ~((((unsigned)k & tmask) << 23) | ((unsigned)k >> lt));
+            if (LDSXYZ) pt[i < NPT ? i : 0] = ~((((unsigned)k & tmask) << 23) | ((unsigned)k >> lt));
             px[i] = xyz[(size_t)k * 3 + 0];
             py[i] = xyz[(size_t)k * 3 + 1];
             pz[i] = xyz[(size_t)k * 3 + 2];
             float mag = (px[i] * px[i] + py[i] * py[i]) + pz[i] * pz[i];
-            td[i] = (mag <= 1e-3f) ? -1.0f : 1e10f;  // -1 marks "never a candidate" (upstream `continue`)
-            if (a.j0 > 0) td[i] = a.td_state[cloud][k];
+            TD(i) = (mag <= 1e-3f) ? -1.0f : 1e10f;  // -1 marks "never a candidate" (upstream `continue`)
+            if (a.j0 > 0) TD(i) = a.td_state[cloud][k];
             lox = fminf(lox, px[i]); loy = fminf(loy, py[i]); loz = fminf(loz, pz[i]);
             hix = fmaxf(hix, px[i]); hiy = fmaxf(hiy, py[i]); hiz = fmaxf(hiz, pz[i]);
         } else {
-            pt[i] = 0u; px[i] = 0.f; py[i] = 0.f; pz[i] = 0.f; td[i] = -1.0f;
+            if (LDSXYZ) pt[i < NPT ? i : 0] = 0u;
+            px[i] = 0.f; py[i] = 0.f; pz[i] = 0.f; TD(i) = -1.0f;
         }
         if (LDSXYZ) {
             s_pts[i * FPS_THREADS + t] = px[i];
@@ -245,9 +265,10 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
     float wmax = 0.0f;                             // the bucket's largest running min-distance, known from the first scan on
     bool scanned = false;                          // (an explicit flag, not a 3e38 sentinel: a box distance that overflows to inf / NaN on
                                                    //  far-out coordinates must not keep a bucket from ever being scanned)
-    long long wk_c = (long long)0x8000000000000000LL;   // cached winner of the bucket {key, local slot | coordinates}
-    int ws_c = 0;
-    float wx_c = 0.f, wy_c = 0.f, wz_c = 0.f;
+    // cached entries of the bucket: its two largest keys {fp32 bits of the running min-distance, tie-break word} + where their points are
+    long long e1k = FPS_IDK, e2k = FPS_IDK;
+    int e1s = 0;
+    float e1x = 0.f, e1y = 0.f, e1z = 0.f, e2x = 0.f, e2y = 0.f, e2z = 0.f;
     float cx = xyz[0], cy = xyz[1], cz = xyz[2];
     if (a.j0 > 0) {   // the previous launch of this stream wrote the last keypoint (kernel boundary: visible)
         const float* lk = a.kpts_out[cloud] + (size_t)(a.j0 - 1) * 3;
@@ -287,195 +308,313 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
     }
     if (a.dbg && blockIdx.x == 0 && t == 0) a.dbg[63] = (fast ? 1 : 0) + 2 * a.colocate + 100 * G;
 
-    for (int j = a.j0 > 0 ? a.j0 : 1; j < a.m; ++j) {
-        const int par = j & 1;
-        const bool tr = a.dbg != nullptr && blockIdx.x == 0 && t == 0 && j >= 1000 && j < 1008;
-        long long* tdp = a.dbg + (j - 1000) * 8;
+    // ---------------------------------------------------------------- the sampling loop, in ROUNDS (round 6)
+    // Rounds 1-5 resolved ONE sample per cross-workgroup exchange: K strictly dependent iterations of (scan -> workgroup reduce ->
+    // publish -> L2 round trip -> reduce over G -> decode) = 1.95 us each, none of it shortened by skipped work (profiles/r05_fps.txt).
+    // A round now resolves SEVERAL samples from one exchange, exactly:
+    //   * every bucket (wave) keeps its TWO largest keys; a workgroup publishes the K largest of its 32 bucket entries with their
+    //     coordinates, plus a BOUND: a key that every point of the workgroup outside the published list stays below (the largest
+    //     unlisted entry, or a listed second-largest -- the rest of that bucket is below it);
+    //   * every workgroup then runs the same deterministic resolution on the same G x K candidates (one per lane of wave 0): take the
+    //     largest key -> that is the next sample (the global arg-max: keys are unique, every workgroup's maximum is listed); apply it to
+    //     the CANDIDATES (td = min(td, d), the very operations of the scan); the next largest candidate key is the next sample as long
+    //     as it is >= the largest bound B -- running min-distances only fall, so no unlisted point can have overtaken it; stop at
+    //     the first candidate below B (or FPS_TMAX samples) and exchange again;
+    //   * the next round starts by applying the resolved samples to the buckets they can change (box test per sample, one lane each).
+    // The sample sequence is the sequential one bit for bit (every FPS test, tilings and tie lattices included); what changes is the
+    // number of exchanges: ~1 per 4-6 samples.
+    const int K = a.kmax < 64 / G ? a.kmax : 64 / G;                            // G K <= 64 lanes of the resolving wave
+    const int cw = lane / K, ce = lane - cw * K;                                 // candidate (workgroup, entry) of this lane in the resolving wave
+    if (t == 0) { s_pick[1][0] = make_float4(cx, cy, cz, 0.f); s_npick[1] = 1; }   // "previous round": the first sample
+    __syncthreads();
+    int j = a.j0 > 0 ? a.j0 : 1;                     // next output index
+    int lastpar = 1;
+    for (unsigned r = 0; j < a.m; ++r) {
+        const int par = (int)(r & 1u), prv = par ^ 1;
+        lastpar = par;
+        const unsigned ep = r + 1u;                  // epoch of this round's granules (the slots are zeroed in front of every launch)
+        const bool tr = a.dbg != nullptr && blockIdx.x == 0 && t == 0 && r >= 100u && r < 108u;
+        long long* tdp = a.dbg + (r - 100u) * 8;
 #define FPS_TR(q) do { if (tr) tdp[q] = __builtin_readcyclecounter(); } while (0)
         FPS_TR(0);
-        // can the new sample lower any running min-distance of this bucket?  d2(c, box), from the same rounded operations as the
-        // point distances below (monotone: <= the computed distance of every point inside the box)
-        bool scan = true;
-        if (a.prune) {
-            const float ex = fmaxf(fmaxf(lox - cx, cx - hix), 0.0f), ey = fmaxf(fmaxf(loy - cy, cy - hiy), 0.0f), ez = fmaxf(fmaxf(loz - cz, cz - hiz), 0.0f);
-            const float db = (ex * ex + ey * ey) + ez * ez;
-            scan = !scanned || __builtin_amdgcn_readfirstlane(db < wmax ? 1 : 0) != 0;
+        // ---- A: the samples of the previous round against this bucket.  Box test of every sample at once (lane q = sample q):
+        //      d2(sample, box) from the same rounded operations as the point distances (monotone: <= the computed distance of every
+        //      point inside the box), so a sample with d2 >= the bucket's largest running min-distance cannot change the bucket
+        const int np = s_npick[prv];
+        unsigned long long hit;
+        {
+            bool h = false;
+            if (lane < np) {
+                h = true;
+                if (a.prune && scanned) {
+                    const float4 q = s_pick[prv][lane];
+                    const float ex = fmaxf(fmaxf(lox - q.x, q.x - hix), 0.0f), ey = fmaxf(fmaxf(loy - q.y, q.y - hiy), 0.0f), ez = fmaxf(fmaxf(loz - q.z, q.z - hiz), 0.0f);
+                    const float db = (ex * ex + ey * ey) + ez * ez;
+                    h = db < wmax;
+                }
+            }
+            hit = __ballot(h);
         }
-        if (scan) {
-            float bd = -1.0f, bx = 0.f, by = 0.f, bz = 0.f;
-            int bi = 0;
-            bool tie = false;
+        // a sample changes the bucket's two cached entries only if it lowers THEIR running min-distances (d < td, the comparison the
+        // update itself makes): every other point can only fall, so untouched entries stay the two largest and the selection is skipped
+        bool upd = false, sel = !scanned;
+        while (hit != 0ULL) {
+            const int q = __ffsll((long long)hit) - 1;
+            hit &= hit - 1ULL;
+            const float4 c4 = s_pick[prv][q];
 #pragma unroll
             for (int i = 0; i < PPT; ++i) {
-                float dx = px[i] - cx, dy = py[i] - cy, dz = pz[i] - cz;
+                float dx = px[i] - c4.x, dy = py[i] - c4.y, dz = pz[i] - c4.z;
                 float d = (dx * dx + dy * dy) + dz * dz;
-                float d2 = fminf(d, td[i]);
-                td[i] = d2;
-                bool better = d2 > bd;
-                tie = tie || (d2 == bd);               // an equal distance inside one thread: decided by the key order below
-                bd = better ? d2 : bd;
-                bi = better ? i : bi;
-                if (!LDSXYZ) {
-                    bx = better ? px[i] : bx;
-                    by = better ? py[i] : by;
-                    bz = better ? pz[i] : bz;
-                }
+                TD(i) = fminf(d, TD(i));
             }
-            unsigned bt = pt[0];
-#pragma unroll
-            for (int i = 1; i < PPT; ++i) bt = bi == i ? pt[i] : bt;
-            if (__any(tie)) {
-                // a thread's points are no longer one residue class of the upstream thread stride (they were k = base + i * 1024 + t before
-                // the spatial order), so "first maximum of the thread" is not the upstream winner when two of them tie: take the larger KEY
-                // (equal distance: lower k mod T, then lower k).  Rare: exact fp32 ties, and threads that hold several non-candidates.
-                bd = td[0]; bi = 0; bt = pt[0];
-#pragma unroll
-                for (int i = 1; i < PPT; ++i) {
-                    const bool better = td[i] > bd || (td[i] == bd && pt[i] > bt);
-                    bd = better ? td[i] : bd; bt = better ? pt[i] : bt; bi = better ? i : bi;
-                }
-                if (!LDSXYZ) {
-                    bx = px[0]; by = py[0]; bz = pz[0];
-#pragma unroll
-                    for (int i = 1; i < PPT; ++i) { bx = bi == i ? px[i] : bx; by = bi == i ? py[i] : by; bz = bi == i ? pz[i] : bz; }
-                }
+            {
+                float dx = e1x - c4.x, dy = e1y - c4.y, dz = e1z - c4.z;
+                const float d1 = (dx * dx + dy * dy) + dz * dz;
+                dx = e2x - c4.x; dy = e2y - c4.y; dz = e2z - c4.z;
+                const float d2 = (dx * dx + dy * dy) + dz * dz;
+                sel = sel || d1 < __int_as_float((int)(e1k >> 32)) || d2 < __int_as_float((int)(e2k >> 32));
             }
-            long long key = ((long long)__float_as_int(bd) << 32) | (long long)bt;
-            // wave max (signed 64-bit) on the DPP network
-            const long long wk = wave_max_key(key);
-            // keys are unique per thread (they embed the point index): the winner's lane broadcasts its slot / coordinates
-            const int wl = __ffsll((long long)__ballot(key == wk)) - 1;
-            wk_c = wk;
-            scanned = true;
-            wmax = __int_as_float((int)(wk >> 32));            // the bucket's largest min-distance (-1: no candidate left)
-            if (LDSXYZ) {
-                ws_c = __builtin_amdgcn_readlane(bi * FPS_THREADS + t, wl);
+            upd = true;
+        }
+        if (upd && sel) {
+            // the bucket's two largest keys.  key = {fp32 bits of the running min-distance, ~tie-break(k)}: unique per point, and its
+            // order IS the upstream rule (larger distance, then lower k mod T, then lower k)
+            long long k1 = FPS_IDK, k2 = FPS_IDK;
+            int i1 = 0, i2 = 0;
+            auto offer = [&](int i, unsigned pti, float tdi) {
+                const long long ki = (long long)(((unsigned long long)(unsigned)__float_as_int(tdi) << 32) | (unsigned long long)pti);
+                const bool b1 = ki > k1, b2 = ki > k2;
+                k2 = b1 ? k1 : (b2 ? ki : k2);
+                i2 = b1 ? i1 : (b2 ? i : i2);
+                k1 = b1 ? ki : k1;
+                i1 = b1 ? i : i1;
+            };
+            if constexpr (LDSTD) {
+                // PPT 16: distances from LDS, tie-break words from the spatial order -- no register array involved, so the loop stays
+                // rolled (unrolled, its sixteen loads in flight cost more registers than the kernel has)
+#pragma unroll 1
+                for (int i = 0; i < PPT; ++i) offer(i, tiebreak(i), TD(i));
             } else {
-                wx_c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx), wl));
-                wy_c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(by), wl));
-                wz_c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bz), wl));
+#pragma unroll
+                for (int i = 0; i < PPT; ++i) offer(i, pt[i < NPT ? i : 0], TD(i));
             }
+            e1k = wave_max_key(k1);
+            const int wl1 = __ffsll((long long)__ballot(k1 == e1k)) - 1;
+            const long long kk = lane == wl1 ? k2 : k1;          // the winner's lane offers its second point
+            const int ii = lane == wl1 ? i2 : i1;
+            e2k = wave_max_key(kk);
+            const int wl2 = __ffsll((long long)__ballot(kk == e2k)) - 1;
+            if (LDSXYZ) {
+                e1s = __builtin_amdgcn_readlane(i1 * FPS_THREADS + t, wl1);
+                const int e2s = __builtin_amdgcn_readlane(ii * FPS_THREADS + t, wl2);
+                e1x = s_pts[e1s]; e1y = s_pts[NP + e1s]; e1z = s_pts[2 * NP + e1s];
+                e2x = s_pts[e2s]; e2y = s_pts[NP + e2s]; e2z = s_pts[2 * NP + e2s];
+            } else {
+                // PPT 16 keeps no LDS copy of the coordinates and no register to spare for select chains over px / py / pz: the two
+                // points are re-read from the cloud by their index (the key's low word; wave-uniform addresses, L2-resident) -- two
+                // loads in flight on the scanning wave only, on clouds beyond 131 072 points only
+                const unsigned tb1 = ~(unsigned)((unsigned long long)e1k & 0xffffffffu), tb2 = ~(unsigned)((unsigned long long)e2k & 0xffffffffu);
+                const int p1 = (int)(((tb1 & 0x7fffffu) << lt) | (tb1 >> 23)), p2 = (int)(((tb2 & 0x7fffffu) << lt) | (tb2 >> 23));
+                const bool v1 = p1 >= 0 && p1 < n, v2 = p2 >= 0 && p2 < n;       // (identity / padding keys decode to nothing: never picked)
+                const float* q1 = xyz + (size_t)(v1 ? p1 : 0) * 3;
+                const float* q2 = xyz + (size_t)(v2 ? p2 : 0) * 3;
+                e1x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q1[0]))); e1y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q1[1])));
+                e1z = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q1[2]))); e2x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q2[0])));
+                e2y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q2[1]))); e2z = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q2[2])));
+                (void)ii; (void)wl1; (void)wl2;
+            }
+            scanned = true;
+            wmax = __int_as_float((int)(e1k >> 32));           // the bucket's largest min-distance (-1: no candidate left)
+        }
+        if (lane == 0) {
+            s_ekey[par][wave] = e1k; s_ekey[par][FPS_WAVES + wave] = e2k;
+            if (LDSXYZ) s_eslot[par][wave] = e1s;
+            else { s_exyz[par][wave][0] = e1x; s_exyz[par][wave][1] = e1y; s_exyz[par][wave][2] = e1z; }
         }
         FPS_TR(1);
-        long long fk;
-        float fx, fy, fz;
-        {
-        if (lane == 0) {
-            s_key[par][wave] = wk_c;
-            if (LDSXYZ) s_slot[par][wave] = ws_c;
-            else { s_xyz[par][wave][0] = wx_c; s_xyz[par][wave][1] = wy_c; s_xyz[par][wave][2] = wz_c; }
-        }
-        FPS_TR(2);
         __syncthreads();
-        FPS_TR(3);
-        if (G == 1) {
-            fk = s_key[par][0]; fx = s_xyz[par][0][0]; fy = s_xyz[par][0][1]; fz = s_xyz[par][0][2];
-            int fs = s_slot[par][0];
-#pragma unroll
-            for (int w = 1; w < FPS_WAVES; ++w) {
-                long long kk = s_key[par][w];
-                bool b = kk > fk;
-                fk = b ? kk : fk;
-                fs = b ? s_slot[par][w] : fs;
-                fx = b ? s_xyz[par][w][0] : fx;
-                fy = b ? s_xyz[par][w][1] : fy;
-                fz = b ? s_xyz[par][w][2] : fz;
+        FPS_TR(2);
+        if (wave == 0) {
+            // lanes 0..15: the largest key of every bucket = the workgroup's candidates; lanes 16..31: the buckets' second largest keys --
+            // everything else in bucket v is below its second key, so their maximum bounds every point that is not a candidate
+            long long ck = FPS_IDK, bk = FPS_IDK;          // candidate key / bound of the candidate's workgroup (resolution inputs)
+            float cxv = 0.f, cyv = 0.f, czv = 0.f;
+            bool act = lane < FPS_WAVES;
+            long long ek2 = FPS_IDK;
+            if (act) {
+                ck = s_ekey[par][lane];
+                ek2 = s_ekey[par][FPS_WAVES + lane];
+                if (LDSXYZ) { const int sl = s_eslot[par][lane]; cxv = s_pts[sl]; cyv = s_pts[NP + sl]; czv = s_pts[2 * NP + sl]; }
+                else { cxv = s_exyz[par][lane][0]; cyv = s_exyz[par][lane][1]; czv = s_exyz[par][lane][2]; }
             }
-            if (LDSXYZ) { fx = s_pts[fs]; fy = s_pts[NP + fs]; fz = s_pts[2 * NP + fs]; }
-        } else {
-            if (wave == 0) {
-                // combine the 16 wave records
-                long long k0 = lane < FPS_WAVES ? s_key[par][lane] : (long long)0x8000000000000000LL;
-                static_assert(FPS_WAVES == 16, "row reduction over the 16 wave records");
-                const long long mk = row_max_key(k0);
-                // the (unique, or lowest) lane holding the max publishes this workgroup's record
-                unsigned long long bal = __ballot(lane < FPS_WAVES && k0 == mk);
-                int src = __ffsll((long long)bal) - 1;
+            static_assert(FPS_WAVES == 16, "row reductions over the sixteen bucket entries");
+            const long long e2max = row_max_key(ek2);      // lanes >= 16 hold the identity
+            bool fail = false;
+            if (G == 1) {
+                bk = e2max;                                // one workgroup: all sixteen bucket maxima are candidates
+            } else {
+                // ---- publish the K largest candidates + the bound.  Rank of every bucket maximum among the sixteen by all-pairs comparison
+                //      (keys broadcast from LDS: independent compares instead of K + 1 dependent DPP reductions on the one wave every other
+                //      wave is waiting for); equal keys (identities, padding) are ordered by lane so that ranks are unique
                 unsigned long long* my = slots + ((size_t)par * FPS_MAX_G + g) * FPS_REC;
-                {   // lanes 0..4 store one granule each: one store instruction, one 40-byte write
-                    unsigned sx, sy, sz;
-                    if (LDSXYZ) {
-                        const int sl = s_slot[par][src];
-                        sx = __float_as_uint(s_pts[sl]); sy = __float_as_uint(s_pts[NP + sl]); sz = __float_as_uint(s_pts[2 * NP + sl]);
-                    } else {
-                        sx = __float_as_uint(s_xyz[par][src][0]); sy = __float_as_uint(s_xyz[par][src][1]);
-                        sz = __float_as_uint(s_xyz[par][src][2]);
-                    }
-                    const unsigned khi = (unsigned)((unsigned long long)mk >> 32), klo = (unsigned)((unsigned long long)mk & 0xffffffffu);
-                    const unsigned v = lane == 0 ? khi : (lane == 1 ? klo : (lane == 2 ? sx : (lane == 3 ? sy : sz)));
-                    if (lane < 5) granule_store(my + lane, ((unsigned long long)(unsigned)j << 32) | v, fast);
-                }
-                FPS_TR(4);
-                // poll: lane w reads the five granules of record w (one 64-byte line per workgroup), so that the checks, the key and
-                // the reduction over the G records are lane-local / one DPP reduction -- no scalar walk over the records
-                unsigned long long r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0;
-                bool fail = false;
+                // fast path on the keys' high words (the fp32 distances): a tie among them that reaches the published ranks takes the exact
+                // 64-bit pass (tie lattices; identities and padding keys tie, but far below rank K)
+                int rank = 0;
                 {
-                    const bool act = lane < G;
-                    unsigned long long* rp = slots + ((size_t)par * FPS_MAX_G + lane) * FPS_REC;
+                    const int h = (int)(ck >> 32);
+                    int eq = 0;
+#pragma unroll
+                    for (int q = 0; q < FPS_WAVES; ++q) {
+                        const int hq = (int)(s_ekey[par][q] >> 32);
+                        rank += hq > h ? 1 : 0;
+                        eq += hq == h ? 1 : 0;
+                    }
+                    if (__any(act && eq > 1 && rank <= K)) {
+                        rank = 0;
+#pragma unroll 1
+                        for (int q = 0; q < FPS_WAVES; ++q) {
+                            const long long kq = s_ekey[par][q];
+                            rank += (kq > ck || (kq == ck && q < lane)) ? 1 : 0;
+                        }
+                    }
+                }
+                if (act && rank < K) {
+                    const unsigned long long eh = (unsigned long long)ep << 32;
+                    unsigned long long* d = my + 2 + rank * 5;
+                    granule_store(d + 0, eh | (unsigned)((unsigned long long)ck >> 32), fast);
+                    granule_store(d + 1, eh | (unsigned)((unsigned long long)ck & 0xffffffffu), fast);
+                    granule_store(d + 2, eh | __float_as_uint(cxv), fast);
+                    granule_store(d + 3, eh | __float_as_uint(cyv), fast);
+                    granule_store(d + 4, eh | __float_as_uint(czv), fast);
+                }
+                // bound: the largest bucket maximum that is not listed (rank K), or the largest second key
+                long long bnd = e2max;
+                {
+                    const unsigned long long mk = __ballot(act && rank == K);
+                    if (mk != 0ULL) {
+                        const int l = __ffsll((long long)mk) - 1;
+                        const long long kl = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)ck >> 32), l) << 32) |
+                                                         (unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)ck & 0xffffffffu), l));
+                        bnd = kl > bnd ? kl : bnd;
+                    }
+                }
+                if (lane < 2) {
+                    const unsigned v = lane == 0 ? (unsigned)((unsigned long long)bnd >> 32) : (unsigned)((unsigned long long)bnd & 0xffffffffu);
+                    granule_store(my + lane, ((unsigned long long)ep << 32) | v, fast);
+                }
+                FPS_TR(3);
+                // ---- poll: lane (workgroup cw, entry ce) reads its candidate's five granules + the two of the workgroup's bound
+                act = lane < G * K;
+                unsigned long long r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, b0 = 0, b1 = 0;
+                {
+                    unsigned long long* rp = slots + ((size_t)par * FPS_MAX_G + (act ? cw : 0)) * FPS_REC + 2 + (act ? ce : 0) * 5;
+                    unsigned long long* bp = slots + ((size_t)par * FPS_MAX_G + (act ? cw : 0)) * FPS_REC;
                     unsigned spins = 0;
                     while (true) {
                         bool ok = true;
                         if (act) {
                             if (fast) {
                                 asm volatile("buffer_inv sc1\n\t"
-                                             "global_load_dwordx2 %0, %5, off\n\t"
-                                             "global_load_dwordx2 %1, %5, off offset:8\n\t"
-                                             "global_load_dwordx2 %2, %5, off offset:16\n\t"
-                                             "global_load_dwordx2 %3, %5, off offset:24\n\t"
-                                             "global_load_dwordx2 %4, %5, off offset:32\n\t"
+                                             "global_load_dwordx2 %0, %7, off\n\t"
+                                             "global_load_dwordx2 %1, %7, off offset:8\n\t"
+                                             "global_load_dwordx2 %2, %7, off offset:16\n\t"
+                                             "global_load_dwordx2 %3, %7, off offset:24\n\t"
+                                             "global_load_dwordx2 %4, %7, off offset:32\n\t"
+                                             "global_load_dwordx2 %5, %8, off\n\t"
+                                             "global_load_dwordx2 %6, %8, off offset:8\n\t"
                                              "s_waitcnt vmcnt(0)"
-                                             : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4) : "v"(rp) : "memory");
+                                             : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(b0), "=&v"(b1) : "v"(rp), "v"(bp) : "memory");
                             } else {
                                 r0 = __hip_atomic_load(rp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 r1 = __hip_atomic_load(rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 r2 = __hip_atomic_load(rp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 r3 = __hip_atomic_load(rp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 r4 = __hip_atomic_load(rp + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                b0 = __hip_atomic_load(bp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                b1 = __hip_atomic_load(bp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             }
-                            const unsigned ep = (unsigned)j;
                             ok = (unsigned)(r0 >> 32) == ep && (unsigned)(r1 >> 32) == ep && (unsigned)(r2 >> 32) == ep &&
-                                 (unsigned)(r3 >> 32) == ep && (unsigned)(r4 >> 32) == ep;
+                                 (unsigned)(r3 >> 32) == ep && (unsigned)(r4 >> 32) == ep && (unsigned)(b0 >> 32) == ep && (unsigned)(b1 >> 32) == ep;
                         }
                         if (__all(ok)) break;
                         if (++spins > FPS_SPIN_LIMIT) { fail = true; break; }
                         __builtin_amdgcn_s_sleep(1);
                     }
                 }
-                FPS_TR(5);
                 if (fail && lane == 0) atomicOr(a.err_flag, 1);
-                const long long rk = lane < G ? (long long)(((unsigned long long)(unsigned)r0 << 32) | (unsigned)r1) : (long long)0x8000000000000000LL;
-                const long long bestk = G <= 16 ? row_max_key(rk) : wave_max_key(rk);
-                // keys embed the point index: one lane holds the maximum (the lowest one, should two ever agree)
-                const int wl = __ffsll((long long)__ballot(lane < G && rk == bestk)) - 1;
-                const float ox = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)(unsigned)r2, wl));
-                const float oy = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)(unsigned)r3, wl));
-                const float oz = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)(unsigned)r4, wl));
-                if (lane == 0) {
-                    s_fkey[par] = bestk;
-                    s_fxyz[par][0] = ox; s_fxyz[par][1] = oy; s_fxyz[par][2] = oz;
+                ck = act ? (long long)(((unsigned long long)(unsigned)r0 << 32) | (unsigned)r1) : FPS_IDK;
+                bk = act ? (long long)(((unsigned long long)(unsigned)b0 << 32) | (unsigned)b1) : FPS_IDK;
+                cxv = __uint_as_float((unsigned)r2); cyv = __uint_as_float((unsigned)r3); czv = __uint_as_float((unsigned)r4);
+            }
+            FPS_TR(4);
+            // ---- resolution: the same inputs and the same operations in every workgroup
+            const long long B = G == 1 ? e2max : wave_max_key(bk);
+            int tlim = a.m - j;
+            tlim = tlim < FPS_TMAX ? tlim : FPS_TMAX;
+            int tc = 0;
+            while (tc < tlim) {
+                const long long bestk = wave_max_key(ck);
+                if (bestk < 0) {
+                    // no candidate anywhere (every point within 1e-3 of the origin, or sampled): upstream yields index 0 -- once per round
+                    if (tc == 0) {
+                        if (lane == 0) { s_pkey[par][0] = bestk; s_pick[par][0] = make_float4(xyz[0], xyz[1], xyz[2], 0.f); }
+                        tc = 1;
+                    }
+                    break;
+                }
+                if (tc > 0 && bestk < B) break;                  // a point outside the lists may have a larger key: exchange again
+                const int wl = __ffsll((long long)__ballot(act && ck == bestk)) - 1;
+                const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cxv), wl));
+                const float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cyv), wl));
+                const float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(czv), wl));
+                if (lane == 0) { s_pkey[par][tc] = bestk; s_pick[par][tc] = make_float4(qx, qy, qz, 0.f); }
+                ++tc;
+                // the sample against the candidates: the operations of the bucket update above
+                {
+                    float dx = cxv - qx, dy = cyv - qy, dz = czv - qz;
+                    float d = (dx * dx + dy * dy) + dz * dz;
+                    // (a lane without a candidate holds the identity key: its high word is -0.0f, which min() keeps)
+                    const float nt = fminf(d, __int_as_float((int)(ck >> 32)));
+                    ck = (long long)(((unsigned long long)(unsigned)__float_as_int(nt) << 32) | ((unsigned long long)ck & 0xffffffffULL));
                 }
             }
-            FPS_TR(6);
-            __syncthreads();
-            fk = s_fkey[par]; fx = s_fxyz[par][0]; fy = s_fxyz[par][1]; fz = s_fxyz[par][2];
-            FPS_TR(7);
+            if (lane == 0) s_npick[par] = tc;
+            FPS_TR(5);
         }
-        }
-        int old;
-        if (fk < 0) {  // no candidate anywhere (all points within 1e-3 of the origin): upstream yields index 0
-            old = 0; fx = xyz[0]; fy = xyz[1]; fz = xyz[2];
-        } else {
-            unsigned tbw = ~(unsigned)((unsigned long long)fk & 0xffffffffu);
-            old = (int)(((tbw & 0x7fffffu) << lt) | (tbw >> 23));
-        }
-        cx = fx; cy = fy; cz = fz;
-        if (g == 0 && t == 0) {
-            a.idx_out[cloud][j] = old;
+        __syncthreads();
+        FPS_TR(6);
+        const int npk = s_npick[par];
+        if (tr) tdp[7] = npk;
+        if (g == 0 && t < npk) {
+            const long long fk = s_pkey[par][t];
+            int old = 0;
+            if (fk >= 0) {
+                const unsigned tbw = ~(unsigned)((unsigned long long)fk & 0xffffffffu);
+                old = (int)(((tbw & 0x7fffffu) << lt) | (tbw >> 23));
+            }
+            const float4 q = s_pick[par][t];
+            a.idx_out[cloud][j + t] = old;
             if (a.kpts_out[cloud]) {
-                a.kpts_out[cloud][(size_t)j * 3 + 0] = cx;
-                a.kpts_out[cloud][(size_t)j * 3 + 1] = cy;
-                a.kpts_out[cloud][(size_t)j * 3 + 2] = cz;
+                a.kpts_out[cloud][(size_t)(j + t) * 3 + 0] = q.x;
+                a.kpts_out[cloud][(size_t)(j + t) * 3 + 1] = q.y;
+                a.kpts_out[cloud][(size_t)(j + t) * 3 + 2] = q.z;
+            }
+        }
+        j += npk;
+    }
+#undef FPS_TR
+    // the samples of the last round have not been applied to the buckets yet: a following launch of a tiled run picks the running
+    // min-distances up from td_state and applies only the LAST keypoint itself (min is idempotent: applying that one twice is harmless)
+    if (a.save) {
+        const int np = s_npick[lastpar];
+        for (int q = 0; q < np; ++q) {
+            const float4 c4 = s_pick[lastpar][q];
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                float dx = px[i] - c4.x, dy = py[i] - c4.y, dz = pz[i] - c4.z;
+                float d = (dx * dx + dy * dy) + dz * dz;
+                TD(i) = fminf(d, TD(i));
             }
         }
     }
@@ -483,11 +622,13 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
 #pragma unroll
         for (int i = 0; i < PPT; ++i)
             if (sp0 + i * 64 < n) {
-                const unsigned tbw = ~pt[i];
-                a.td_state[cloud][(int)(((tbw & 0x7fffffu) << lt) | (tbw >> 23))] = td[i];
+                const unsigned tbw = ~(LDSXYZ ? pt[i < NPT ? i : 0] : tiebreak(i));
+                a.td_state[cloud][(int)(((tbw & 0x7fffffu) << lt) | (tbw >> 23))] = TD(i);
             }
     }
 }
+
+#undef TD
 
 // ---- spatial order of a cloud (bucket pruning): Morton curve over 16 x 16 x 16 cells of the bounding box, counting sort.  The order
 //      inside a cell is whatever the atomics produce -- it decides which bucket a point sits in, never the sampling result.
@@ -639,12 +780,16 @@ int bxk_fps_range(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* 
         BX_HIP(hipMemsetAsync(c->fps_hello, 0, sizeof(unsigned long long) * FPS_MAX_CLOUDS * FPS_MAX_G, s));
         total = 8 * gmax;
     }
-    // epochs continue across the launches of a tiled run: the slots are cleared once, in front of the first one
-    if (j0 == 0) BX_HIP(hipMemsetAsync(c->fps_slots, 0, sizeof(unsigned long long) * FPS_MAX_CLOUDS * 2 * FPS_MAX_G * FPS_REC, s));
+    // the epochs of a launch start at 1: the slots are cleared in front of every launch (tiled runs included)
+    BX_HIP(hipMemsetAsync(c->fps_slots, 0, sizeof(unsigned long long) * FPS_MAX_CLOUDS * 2 * FPS_MAX_G * FPS_REC, s));
     // the spatial order of the clouds (bucket pruning), once per run
     {
         const char* ep = getenv("BX_FPS_PRUNE");       // test / measurement hook: 0 = scan every bucket in every iteration
         a.prune = ep ? atoi(ep) : 1;
+        const char* ek = getenv("BX_FPS_K");          // measurement hook: candidates per workgroup and round (results do not depend on it)
+        a.kmax = ek ? atoi(ek) : 4;
+        if (a.kmax < 1) a.kmax = 1;
+        if (a.kmax > FPS_K) a.kmax = FPS_K;
         // a cloud beyond the context's max_points (stage entry point only: bx_register_pair checks its clouds) has no room for its order:
         // it is sampled in input order -- buckets that are not compact are rarely skipped, the result is the same
         bool ordered = true;
@@ -666,9 +811,10 @@ int bxk_fps_range(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* 
             hipLaunchKernelGGL(fps_scatter_kernel, dim3((nmax + 255) / 256, nclouds), dim3(256), 0, s, o);
         }
     }
-    const size_t lds = ppt <= 8 ? (size_t)3 * ppt * FPS_THREADS * sizeof(float) : 0;     // PPT 8: 96 KiB
+    const size_t lds = ppt <= 8 ? (size_t)3 * ppt * FPS_THREADS * sizeof(float) : (size_t)16 * FPS_THREADS * sizeof(float);     // PPT 8: 96 KiB of coordinates; PPT 16: 64 KiB of running min-distances
     if (lds > 48 * 1024 && !c->fps_attr_set) {
         BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        BX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         c->fps_attr_set = 1;
     }
     if (ppt == 4) hipLaunchKernelGGL(fps_kernel<4>, dim3(total), dim3(FPS_THREADS), lds, s, a);

@@ -25,7 +25,7 @@ for n in [int(a) for a in sys.argv[1:]] or [38000]:
     for it in range(3):
         ctx.register_pair_async(src, tgt, pair["aligned_z"], ps, pt, 5); st.synchronize()
     pr = ctx.profile_read()
-    print("n", ns, nt, "PPT", os.environ.get("BX_FPS_PPT", "auto"), "fps ms %.3f" % (pr["fps"][0] / pr["fps"][1]), "us/iter %.3f" % (pr["fps"][0] / pr["fps"][1] / m * 1e3), flush=True)
+    print("n", ns, nt, "PPT", os.environ.get("BX_FPS_PPT", "auto"), "fps ms %.3f" % (pr["fps"][0] / pr["fps"][1]), "us/sample %.3f" % (pr["fps"][0] / pr["fps"][1] / m * 1e3), flush=True)
     if os.environ.get("BX_FPS_TRACE"):
         import ctypes as C
         buf = (C.c_int64 * 64)()
@@ -33,9 +33,9 @@ for n in [int(a) for a in sys.argv[1:]] or [38000]:
         rc = ctx.lib.bx_debug_read(ctx.handle, buf, 64)
         print("flags (fast + 2*colocate + 100*G):", buf[63])
         a = np.array(buf[:], np.int64).reshape(8, 8)
-        print("stamps (cycles rel. to iteration start): compute | wave-reduce+lds | barrier1 | wg-reduce+publish | poll | gather | barrier2+read ; next-iter gap")
+        print("round stamps (cycles): apply + entries | barrier 1 | publish K entries + bound | poll | resolve | barrier 2 ; samples resolved ; gap to the next round")
         for r in range(8):
-            d = a[r] - a[r, 0]
-            gap = (a[r + 1, 0] - a[r, 7]) if r < 7 else 0
-            print("  ", [int(d[i] - d[i - 1]) for i in range(1, 8)], "total", int(d[7]), "gap", int(gap))
+            d = a[r, :7] - a[r, 0]
+            gap = (a[r + 1, 0] - a[r, 6]) if r < 7 else 0
+            print("  ", [int(d[i] - d[i - 1]) for i in range(1, 7)], "total", int(d[6]), "samples", int(a[r, 7]), "gap", int(gap))
     ctx.close()
