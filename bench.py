@@ -75,7 +75,7 @@ def profile_json(name, files=()):
         now = sha_map()
     except Exception:
         now = {}
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_%s.json" % (rnd, name))) as f:
                 d = json.load(f)
@@ -488,6 +488,10 @@ def main():
                         "beside the sampling of the next"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl_text % (S, K, P),
+                       # the metric's second half where the driver keeps it (it stores `config`, not the extra top-level keys):
+                       # service time of ONE pair alone, throughput form / latency form (keypoint_tiles)
+                       "p50_ms_per_pair": round(float(np.median(lat1)), 3),
+                       "p50_ms_per_pair_latency_form": None if lat1t is None else round(float(np.median(lat1t)), 3),
                        "pairs_in_flight_per_gpu": C, "arithmetic_forms": forms, "distinct_pairs": len(pairs), "parallelism": "pair-sharded x%d, one all-gather of %d B float64 records" % (world, 8 * D.RECORD),
                        "weights": "seeded random (reference snapshot layout)", "mean_points_per_cloud": nmean,
                        "workload_generator": "synth.make_pair v2 (round 2+: shared=True noise-free partial-overlap fragments; round 1 used "

@@ -77,7 +77,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // One thread per query, the references of a tile in LDS, TWO references per step as packed fp32 (v_pk_add_f32 / v_pk_fma_f32: the
 // squared distance of a (query, reference) pair is still the fmaf chain over d = 0..31 from 0 -- the two chains of a step are the two
 // halves of one packed register, the query component is broadcast to both).  LDS layout [reference pair][d][2]: a ds_read_b128
-// delivers two components of both references.  Half the VALU instructions of the scalar form (round 3: 109 -> see DESIGN.md).
+// delivers two components of both references.  Half the VALU instructions of the scalar form (round 3: 109 -> see LABBOOK.md).
 __global__ __launch_bounds__(256) void nn1_kernel(const float* __restrict__ qd, int nq, const float* __restrict__ rd, int nr,
                                                   int seg_len, unsigned long long* __restrict__ keys, const int32_t* __restrict__ skip)
 {

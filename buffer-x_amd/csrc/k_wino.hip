@@ -15,7 +15,7 @@
 // r_xi[j] = (M0 + M1) + M2 | (M1 - M2) - M3 lane-locally and hands its two quantities -- half 0: r0 + r1 and r1, half 1: r2 and r3 --
 // to an LDS exchange (bytes of the consumed plane set) that all threads then read in output order: Y[0][j] = ((r0 + r1) + r2),
 // Y[1][j] = ((r1 - r2) - r3), + bias, ReLU, 16-byte stores.  The round-3 one-unit pipelined kernel (transform of one wave beside the
-// MFMAs of its SIMD sibling: 8 100 cycles per unit and chunk against 7 170 serialised) was removed in round 4; DESIGN.md section 2 keeps
+// MFMAs of its SIMD sibling: 8 100 cycles per unit and chunk against 7 170 serialised) was removed in round 4; LABBOOK.md section 2 keeps
 // its measurements.
 #include "bx_common.h"
 #include <cstdlib>

@@ -4,7 +4,7 @@ non-dyadic constants up to 8 / down to 1/24, so intermediate values are amplifie
 emulates the fp32 pipeline (input transform, per-plane channel contraction, output transform all rounded to fp32; filter transform in
 binary64 rounded once, like the shipped F(2x2) form) on realistic activations (the exact layers 0..2 of the descriptor stack on
 |N(0,1)| features, through the oracle) and reports the error against a binary64 convolution next to the F(2x2, 3x3) form and the direct
-fp32 form.  Run:  python tests/study_wino43_error.py   (prints one JSON object; DESIGN.md section 2 quotes it)."""
+fp32 form.  Run:  python tests/study_wino43_error.py   (prints one JSON object; LABBOOK.md section 2 quotes it)."""
 import json
 import os
 import sys

@@ -1,6 +1,6 @@
 """Degenerate correspondence counts through bx_register_pair, as named tests (round 4).
 
-Where the reference raises or hands an ill-posed problem to a library, the product has a documented behaviour:
+Where the reference raises or hands an ill-posed problem to a library, the product has a documented behaviour (LABBOOK.md section 4):
  * m = 1 mutual match (reference: CostVolume squeezes a batch of one away, models/BUFFERX.py:66): CostNet runs on the one match, the pair
    continues;
  * C = |inlier_ind| < 3 (reference: Open3D's registration_ransac_based_on_correspondence with fewer than ransac_n = 3 correspondences

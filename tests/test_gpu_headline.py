@@ -252,7 +252,7 @@ def test_headline_vs_reference(headline, bx, golden_dir):
     tests/golden/ref_harness.py): identical counts (RANSAC inliers, accumulated mutual matches, consensus set, scales used), radii,
     per-scale mutual sets and consensus set, and the pose within the north-star tolerance 1e-4 deg / 1e-4 m.  The number of
     descriptor rows that differ beyond 2e-5 (a point within an ulp of a radius / voxel bound decided differently by the reference's
-    torch / numpy arithmetic) is reported AND bounded (0.4 % of the sampled rows): DESIGN.md section 4 quotes it."""
+    torch / numpy arithmetic) is reported AND bounded (0.4 % of the sampled rows): LABBOOK.md section 4 quotes it."""
     g = np.load(golden_path(headline["name"]))
     pair, used = headline["pair"], headline["used"]
     assert np.array_equal(pair["src"][:8], g["src_head"]) and np.array_equal(pair["tgt"][:8], g["tgt_head"])

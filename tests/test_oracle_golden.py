@@ -65,7 +65,7 @@ def test_oracle_pipeline_matches_reference(bx, packed, golden_dir, name):
     assert scales == int(g["scales_used"])
     # BASELINE configs[0] size (512 keypoints x 512 points on 18k-point clouds): a handful of patches hold a point whose distance sits
     # within an ulp of the radius / voxel bound, where the numpy stand-ins of the un-vendored CUDA ops (ref_harness.py) and the
-    # oracle's arithmetic contract may decide differently (4 of 1024 descriptor rows differ at the 1e-3 level).
+    # oracle's arithmetic contract may decide differently (4 of 1024 descriptor rows differ at the 1e-3 level; LABBOOK.md section 4).
     # There: >= 99 % of the rows within the strict bound and every row within 1e-2; the small cases stay strict for every row.
     big = name == "baseline_cfg0" or name in MID
 
@@ -118,13 +118,13 @@ def test_oracle_pipeline_matches_reference(bx, packed, golden_dir, name):
 # ------------------------------------------------------------------ the real-size fixtures (K = 5000 / P = 1024 / S = 3)
 # smallest fraction of the sampled descriptor rows of one (scale, cloud) within 2e-5 of the reference's, per fixture: the z-aligned
 # configurations agree in every row; the un-aligned (indoor) ones have a few rows per thousand with a point within an ulp of a radius /
-# voxel bound
+# voxel bound (LABBOOK.md section 4)
 BIG_ROWS_MIN_FRAC = {"headline_cfg1": 0.997, "kitti_cfg2": 1.0, "tiers_early": 1.0, "headline_cfg1_b": 0.995, "headline_cfg1_c": 0.997,
                      "kitti_cfg2_b": 1.0, "headline_lo": 0.996}     # observed 0.9976 / 1 / 1 / 0.9952 / 0.9976 / 1 / 0.9968 (of 1 250 rows)
 BIG_NAMES = ["headline_cfg1", "kitti_cfg2", "tiers_early", "headline_cfg1_b", "headline_cfg1_c", "kitti_cfg2_b", "headline_lo"]
 
 
-@pytest.mark.skipif(not os.environ.get("BX_RUN_BIG_ORACLE"), reason="3-4 CPU-minutes per case: set BX_RUN_BIG_ORACLE=1 (results quoted in DESIGN.md section 4)")
+@pytest.mark.skipif(not os.environ.get("BX_RUN_BIG_ORACLE"), reason="3-4 CPU-minutes per case: set BX_RUN_BIG_ORACLE=1 (results quoted in LABBOOK.md section 4)")
 @pytest.mark.parametrize("name", BIG_NAMES)
 def test_oracle_matches_reference_at_real_size(bx, packed, golden_dir, name):
     """The CPU oracle pipeline against the fixture minted by the reference's own forward at BASELINE configs[1] / [2] / [4] size: radii,

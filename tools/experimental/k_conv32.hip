@@ -6,7 +6,7 @@
 // but on 32 x 32 output tiles: one MFMA covers 32 positions x 32 channels x 2 input channels in 64 matrix-pipe cycles and its
 // issue interval equals its dependent-accumulator latency, so ONE wave per SIMD keeps the pipe full with one accumulator chain.
 //
-// Structure (found with in-kernel cycle stamps and SQ_VALU_MFMA_BUSY_CYCLES):
+// Structure (found with in-kernel cycle stamps and SQ_VALU_MFMA_BUSY_CYCLES, LABBOOK.md §2):
 //   * On gfx950 the f32 MFMA runs at the f32 VECTOR rate.  Two waves that both stream f32 MFMAs on one SIMD reach only ~80 % of
 //     the pipe (measured: 2 workgroups x 4 waves per CU, 81 % busy once their non-MFMA phases had been shrunk to nothing), one
 //     wave alone ~95 %; and while a wave streams MFMAs, a co-resident wave's VALU instruction gets in only at an MFMA boundary

@@ -3,7 +3,7 @@
 // per wave and round, rows re-packed every round (PF_ROUNDS = 1).  Bit-exact (tests/test_gpu_stages.py, test_gpu_pipeline.py pass with
 // it) and ~45 % fewer query instructions, but SLOWER: 375 / 356 / 289 us per launch at the three scales against 282 / 263 / 222 us for
 // the three-rows-per-wave form with the same hit recording (K = 5000, P = 1024, tools/bench_stage.py patch): only four of the eight
-// waves have work in a round and every round ends in a workgroup barrier, so the patch holds its LDS longer.
+// waves have work in a round and every round ends in a workgroup barrier, so the patch holds its LDS longer (LABBOOK.md section 2).
 // To try it again: copy over buffer-x_amd/csrc/k_patch.hip and build with tools/build_variant.sh.
 // k_patch.hip -- patch -> cylindrical voxel features, fused:
 //   axis_align   (reference models/patch_embedder.py:122-148; utils/common.py:709-726 cal_Z_axis,

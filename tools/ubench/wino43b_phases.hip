@@ -1,7 +1,7 @@
 // micro-benchmark 5 (round 6): the PHASES of a Winograd-domain 3 x bf16 split form of the F(4x4, 3x3) Cylindrical_Net kernel, as
 // skeletons with the real instruction mix and the real LDS / register / L2 footprints -- before anybody writes the kernel.
 //
-// The form (DESIGN.md "bf16 x 3 costing"): V = B^T d B in fp32 as today, then every V element is split into three bf16 parts
+// The form: V = B^T d B in fp32 as today, then every V element is split into three bf16 parts
 // (hi = rn(v), mid = rn(v - hi), lo = rn(v - hi - mid): 8 + 8 + 8 significand bits, v = hi + mid + lo to 2^-26), the pre-split filter
 // transform U likewise, and a plane's channel contraction is SIX bf16 MFMAs (hh, hm, mh, hl, lh, mm) with fp32 accumulation instead of
 // the f32 MFMAs: 6 / 16 of today's matrix-pipe time.  What that costs elsewhere is what this file measures, one phase per launch:
