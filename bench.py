@@ -42,6 +42,9 @@ DESC_CONV_MMAC_PER_PATCH = 3.871 + 5.161 + 10.322 + 20.644 + 10.322 + 5.161 + 2.
 #  winograd22: layers 0..5 (>= 64 output channels) 16 planes x 40 tile rows per two units = 640 / 1260, layers 6, 7 direct
 DESC_EXECUTED_MMAC_PER_PATCH = {
     "winograd43": DESC_CONV_MMAC_PER_PATCH * 360.0 / 1260.0,
+    # mixed tiles (round 6): 36 planes on the F(4x4) tiles of the map rows 0..3 + 30 on the F(3x4) tiles of the rows 4..6 = 66 plane-rows per
+    # column block, 330 per unit (the 24 MFMAs a wave skips are really not issued)
+    "winograd43m": DESC_CONV_MMAC_PER_PATCH * 330.0 / 1260.0,
     "winograd22": (3.871 + 5.161 + 10.322 + 20.644 + 10.322 + 5.161) * 640.0 / 1260.0 + 2.580 + 1.290,
     "direct": DESC_CONV_MMAC_PER_PATCH,
 }
@@ -148,7 +151,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=16, help="pairs in flight per GPU (contexts / HIP streams); measured 8 / 12 / 16 / 24 / 32: 50.8 / 51.9 / 52.6 / 49.7 / 50.6 pairs/s")
     ap.add_argument("--lane", type=int, default=0, help="bx_lane mode ordering the pairs in flight: 0 none, 1 whole main phase, 2 conv stacks")
     ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic pairs (cycled; the same list on every rank); N of every cloud is drawn from U[20k, 60k]")
-    ap.add_argument("--desc-conv", default=None, choices=["winograd43", "winograd22", "direct"], help="bx_params.desc_conv_form (default: the library default)")
+    ap.add_argument("--desc-conv", default=None, choices=["winograd43", "winograd22", "direct", "winograd43m"], help="bx_params.desc_conv_form (default: the library default)")
     ap.add_argument("--pose-conv", default=None, choices=["winograd43", "winograd22", "direct"], help="bx_params.pose_conv_form")
     ap.add_argument("--cost-l0", default=None, choices=["collapsed", "direct"], help="bx_params.cost_l0_form")
     ap.add_argument("--inflight-sweep", default="1,2,4,8,16", help="pairs in flight of the throughput-vs-latency sweep after the timed region ('' = skip)")
@@ -394,6 +397,7 @@ def main():
             ex_mmac = DESC_EXECUTED_MMAC_PER_PATCH[form]
             ex_ach = 2.0 * ex_mmac * 1e6 * K / (conv_ms / conv_n * 1e-3) / 1e12
             roof = {"kernel": {"winograd43": "wino43_kernel<...> x8 (Winograd F(4x4,3x3), items of 32 tile rows; every layer)",
+                               "winograd43m": "wino43m_kernel<...> x8 (mixed Winograd tiles: F(4x4,3x3) rows 0..3 + F(3x4,3x3) rows 4..6, items of 16 column blocks; every layer)",
                                "winograd22": "wino_pair_kernel<...> x6 (Winograd F(2x2,3x3), two units per workgroup) + conv_kernel<...> x2",
                                "direct": "conv_kernel<...> x8"}[form] + " (Cylindrical_Net stack, f32 MFMA)",
                     "bound": "mfma",

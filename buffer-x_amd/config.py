@@ -31,7 +31,7 @@ class Cfg(dict):
 # Arithmetic forms of the three stages that have more than one (include/bufferx.h bx_params.desc_conv_form / pose_conv_form /
 # cost_l0_form; no reference counterpart: the reference leaves the summation order of its convolutions to cuDNN / ATen).  Index in the
 # tuple = the C-ABI value; the first entry of each is the default.  cfg.arith carries the names; the oracle takes the same names.
-ARITH_FORMS = {"desc_conv": ("winograd43", "winograd22", "direct"), "pose_conv": ("winograd43", "winograd22", "direct"), "cost_l0": ("collapsed", "direct")}
+ARITH_FORMS = {"desc_conv": ("winograd43", "winograd22", "direct", "winograd43m"), "pose_conv": ("winograd43", "winograd22", "direct"), "cost_l0": ("collapsed", "direct")}
 # what make_cfg puts into cfg.arith.  tests/conftest.py --arith overrides it for a whole test run (every form is covered that way);
 # nothing reads the process environment.
 ARITH_DEFAULT = {k: v[0] for k, v in ARITH_FORMS.items()}

@@ -395,7 +395,7 @@ static int create_impl(bx_ctx* c, int device_id)
         e = getenv("BX_RAD_SLICES");                 // measurement hook (k_radius.hip); results do not depend on it
         c->rad_slices = e ? atoi(e) : 0;
         // arithmetic forms: bx_params (validated by bx_create), never the environment
-        c->use_wino = p.desc_conv_form == BX_DESC_CONV_DIRECT ? 0 : (p.desc_conv_form == BX_DESC_CONV_WINOGRAD22 ? 1 : 2);
+        c->use_wino = p.desc_conv_form == BX_DESC_CONV_DIRECT ? 0 : (p.desc_conv_form == BX_DESC_CONV_WINOGRAD22 ? 1 : (p.desc_conv_form == BX_DESC_CONV_WINOGRAD43M ? 3 : 2));
         c->use_wino_pose = p.pose_conv_form == BX_POSE_CONV_DIRECT ? 0 : (p.pose_conv_form == BX_POSE_CONV_WINOGRAD22 ? 1 : 2);
         c->cost_direct = p.cost_l0_form == BX_COST_L0_DIRECT ? 1 : 0;
     }
@@ -466,7 +466,7 @@ int bx_create(int device_id, const bx_params* params, bx_ctx** out)
         bx_set_error("bx_create: invalid parameters");
         return BX_ERR_ARG;
     }
-    if (p.desc_conv_form < 0 || p.desc_conv_form > BX_DESC_CONV_DIRECT || p.pose_conv_form < 0 || p.pose_conv_form > BX_POSE_CONV_DIRECT ||
+    if (p.desc_conv_form < 0 || p.desc_conv_form > BX_DESC_CONV_WINOGRAD43M || p.pose_conv_form < 0 || p.pose_conv_form > BX_POSE_CONV_DIRECT ||
         p.cost_l0_form < 0 || p.cost_l0_form > BX_COST_L0_DIRECT) {
         bx_set_error("bx_create: unknown arithmetic form (desc_conv_form %d, pose_conv_form %d, cost_l0_form %d)", p.desc_conv_form,
                      p.pose_conv_form, p.cost_l0_form);
@@ -637,6 +637,7 @@ int bx_load_weights(bx_ctx* c, const bx_weights* w)
         if ((rc = upload_w(L, w->desc_w[l])) != BX_OK) return rc;
         if (c->use_wino == 1 && L.cout >= 64 && (rc = bxk_wino_weights(w->desc_w[l], L.nchunk, 1, L.cout, &L.Wwino)) != BX_OK) return rc;
         if (c->use_wino == 2 && (rc = bxk_wino43_weights(w->desc_w[l], L.nchunk, 1, L.cout, &L.Wwino43)) != BX_OK) return rc;
+        if (c->use_wino == 3 && (rc = bxk_wino43m_weights(w->desc_w[l], L.nchunk, L.cout, &L.Wwino43)) != BX_OK) return rc;
         if ((rc = upload(&L.b, w->desc_b[l], (size_t)L.cout)) != BX_OK) return rc;
         if ((rc = upload_geo(L, cg)) != BX_OK) return rc;
     }

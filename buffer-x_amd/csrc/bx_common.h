@@ -189,7 +189,7 @@ struct bx_ctx {
     int wino43v_cap[BX_NPOSE];          // persistent grid of the valid F(4x4) kernels (k_wino43v.hip)
     int wino_pose_cap[BX_NPOSE];
     int use_wino_pose;                  // bx_params.pose_conv_form: 1 = winograd (valid F(2x2, 3x3), k_wino.hip), 2 = winograd43 (valid F(4x4, 3x3), k_wino43v.hip), 0 = direct -- CostNet layers 1..5
-    int use_wino;                       // bx_params.desc_conv_form: 2 = winograd43 (F(4x4, 3x3), every layer), 1 = winograd22 (F(2x2, 3x3), layers with >= 64 output channels), 0 = direct
+    int use_wino;                       // bx_params.desc_conv_form: 3 = winograd43m (mixed F(4x4) / F(3x4) tiles, every layer; fragments in Wwino43), 2 = winograd43 (F(4x4, 3x3), every layer), 1 = winograd22 (F(2x2, 3x3), layers with >= 64 output channels), 0 = direct
     int conv_persist, conv_cap_override, n_cu;
     int rad_slices;                     // measurement hook BX_RAD_SLICES: point slices of radius_hist_kernel (0 = the default, 16)
     double *d_cost_wp, *d_cost_wq;      // collapsed CostNet layer 0 (k_cost.hip): binary64 weights of the P / Q convolutions
@@ -231,6 +231,8 @@ int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, cons
 int bxk_wino43_weights(const float* w, int nchunk, int fold, int cout, float** d_out);
 int bxk_wino43v(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t* units_dev, int max_units, float* out);
 int bxk_wino43(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t* units_dev, int max_units, float* out);
+int bxk_wino43m(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t* units_dev, int max_units, float* out);   // mixed tiles (k_wino43m.hip)
+int bxk_wino43m_weights(const float* w, int nchunk, int cout, float** d_out);
 int bxk_wino(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t* units_dev, int max_units, float* out);
 int bxk_wino_weights(const float* w, int nchunk, int fold, int cout, float** d_out);
 int bxk_wino_pose(bx_ctx* c, hipStream_t s, int layer, const float* in, const int32_t* units_dev, int max_units, float* out);

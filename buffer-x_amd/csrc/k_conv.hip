@@ -559,6 +559,10 @@ int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, cons
 {
     constexpr int CYL = (BX_ELE + 2) * (BX_AZI + 2);   // 198 LDS rows per unit: cylindrical map + halo
     if (max_units < 1) return BX_OK;                   // an empty launch is not an error in any form (bx_desc_net(K = 0), bx_conv_layer(units = 0))
+    if (net == 0 && c->use_wino == 3) {
+        const int rcm = bxk_wino43m(c, s, layer, in, units_dev, max_units, out);                          // mixed F(4x4) / F(3x4) tiles: every layer
+        if (rcm >= 0) return rcm;
+    }
     if (net == 0 && c->use_wino == 2) {
         const int rc43 = bxk_wino43(c, s, layer, in, units_dev, max_units, out);                          // F(4x4, 3x3): every layer
         if (rc43 >= 0) return rc43;

@@ -48,6 +48,9 @@
 #ifndef BX_W43_EARLYREQ
 #define BX_W43_EARLYREQ 1          // slab pieces of the next chunk requested BEFORE the transform and written late in the MFMA loop (0: the round-4 first form)
 #endif
+#ifndef BX_W43_SWAPXY
+#define BX_W43_SWAPXY 0            // 1: 128-column layers with the column block as the fast grid dimension (XCD parity = column block): measured +-0 (r06h)
+#endif
 #ifndef BX_W43_STAMP
 #define BX_W43_STAMP 0             // 1: instrumented build (tools/build_variant.sh): s_memtime phase stamps of workgroup (0, 0) into bx_debug_read
 #endif
@@ -136,10 +139,15 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = wave & 1, ctl = wave >> 1;
     const bool cw = ctl < NCW;                      // compute wave (MFMAs + output); with CW = 32 waves 4..7 only stage and transform
-    const int ctg = (int)blockIdx.y * NCW + (cw ? ctl : 0);
+    // block = (item walker bxi, column block byi).  With two column blocks per layer (COUT = 128) the COLUMN block is the fast grid dimension:
+    // workgroup -> XCD placement follows the linear block id modulo 8, so even XCDs then hold column block 0 and odd XCDs column block 1,
+    // and an XCD's L2 keeps HALF of the layer's U fragments (1.2 instead of 2.4 MB for the 128 -> 128 layer) beside the streamed maps
+    constexpr bool SWAPXY = BX_W43_SWAPXY && (COUT / CW == 2);
+    const int bxi = SWAPXY ? (int)blockIdx.y : (int)blockIdx.x, byi = SWAPXY ? (int)blockIdx.x : (int)blockIdx.y;
+    const int ctg = byi * NCW + (cw ? ctl : 0);
     const int li = lane & 15, kk = lane >> 4;
     const int ngroups = (units * NT4 + ROWS4 - 1) / ROWS4;          // items of 32 tile rows
-    if ((int)blockIdx.x >= ngroups) return;
+    if (bxi >= ngroups) return;
 
     for (int i = tid; i < (int)(W43_LDS / 16); i += CT) reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -228,15 +236,15 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
 
     // (group, chunk) walk of the slab pipeline: the slab holds the chunk being transformed, st the pieces of the chunk after it,
     // requests go out for the one after that
-    int ug = blockIdx.x;
-    const int gstep = (int)gridDim.x;
+    int ug = bxi;
+    const int gstep = SWAPXY ? (int)gridDim.y : (int)gridDim.x;
     int lg = ug, lc = 0;                            // the (group, chunk) the NEXT request fetches
     auto ladv = [&]() { if (++lc == NCHUNK) { lc = 0; lg += gstep; } };
 #pragma unroll
     for (int q = 0; q < NLD; ++q) gload1(q, lg, lc);
     ladv();
     __syncthreads();                 // zero fill complete
-    if (tid < CW) Vp[NPL * VPL4 + (tid >> 4) * 16 + (tid & 3) * 4 + ((tid & 15) >> 2)] = bias[(int)blockIdx.y * CW + tid];
+    if (tid < CW) Vp[NPL * VPL4 + (tid >> 4) * 16 + (tid & 3) * 4 + ((tid & 15) >> 2)] = bias[byi * CW + tid];
 #pragma unroll
     for (int q = 0; q < NLD; ++q) lwrite1(q);
     bool st_live = lg < ngroups;
@@ -382,7 +390,7 @@ __global__ __launch_bounds__(CT, 2) void wino43_kernel(const float* __restrict__
         if (ug >= ngroups) break;
     }
 #if BX_W43_STAMP
-    if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == 3)) {
+    if (dbg && bxi == 0 && byi == 0 && lane == 0 && (wave == 0 || wave == 3)) {
         long long* d = dbg + (wave ? 8 : 0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) d[i] = (long long)st_acc[i];
@@ -412,7 +420,8 @@ int launch_wino43(bx_ctx* c, int layer, hipStream_t s, const ConvLayerDev& L, co
     int grid = (units * NT4 + ROWS4 - 1) / ROWS4;
     if (grid <= 0) return BX_OK;
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(k, dim3(grid, COUT / CW), dim3(CT), W43_LDS, s, in, units, L.Wwino43, L.b, out, c->skip,
+    const bool swapxy = BX_W43_SWAPXY && COUT / CW == 2;
+    hipLaunchKernelGGL(k, swapxy ? dim3(COUT / CW, grid) : dim3(grid, COUT / CW), dim3(CT), W43_LDS, s, in, units, L.Wwino43, L.b, out, c->skip,
                        BX_W43_STAMP ? reinterpret_cast<long long*>(c->ball_dbg) + 16 * layer : nullptr);
     BX_LAUNCH_CHECK();
     return BX_OK;

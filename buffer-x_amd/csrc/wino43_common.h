@@ -119,4 +119,92 @@ __device__ __forceinline__ void wino43_finish(const f32x2 (&A)[2][4], const f32x
     }
 }
 
+// ---- mixed tiles (k_wino43m.hip, bx_params.desc_conv_form = winograd43m): the F(3x4, 3x3) tiles of the map rows 4..6.  F(3, 3) on the
+// points {1, -1, 1/2, -1/2, inf} down the rows (contract: oracle/bx_oracle.c::bxo_conv_wino43m): B3^T of a 5-vector, and the two halves of
+// the output transform.  Wave half 0 holds the planes xi = 0..2, half 1 the planes xi = 3, 4:
+//   half 0: p = r_0 + r_1, q = r_0 - r_1: keeps A = p + r_2 (output row 0), B = fma(.5, r_2, q) (row 1); sends fma(.25, r_2, p) (row 2)
+//   half 1: keeps A = fma(.25, r_3, r_4) (row 2); sends r_3 (row 0) and -.5 r_3 (row 1)
+__device__ __forceinline__ void bt5s(float d0, float d1, float d2, float d3, float d4, float (&o)[5])
+{
+    o[0] = fmaf(4.0f, d2 + d3, -(d0 + d1));
+    o[1] = fmaf(4.0f, d3 - d2, d0 - d1);
+    const float a = d2 - d0, b = d3 - d1;
+    o[2] = fmaf(2.0f, b, a);
+    o[3] = fmaf(2.0f, b, -a);
+    o[4] = fmaf(4.0f, d4, fmaf(-5.0f, d2, d0));
+}
+
+template <int HALF>
+__device__ __forceinline__ void wino43m_send(const f32x4 (&acc)[NPH][RT4], int rt, f32x2 (&A)[2][4], f32x2 (&B)[2][4], float4* mine)
+{
+    f32x4* mine4 = reinterpret_cast<f32x4*>(mine);
+    constexpr int NX = HALF == 0 ? 3 : 2;
+    f32x2 s0[2][4], s1[2][4];
+#pragma unroll
+    for (int rp = 0; rp < 2; ++rp) {
+        f32x2 rr[NX][4];
+#pragma unroll
+        for (int x = 0; x < NX; ++x) {
+            f32x2 m[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) m[k] = rp == 0 ? lo2(acc[x * 6 + k][rt]) : hi2(acc[x * 6 + k][rt]);
+            const f32x2 p = m[1] + m[2], q = psub(m[1], m[2]), s = m[3] + m[4], t = psub(m[3], m[4]);
+            rr[x][0] = (m[0] + p) + s;
+            rr[x][1] = pfma(2.0f, t, q);
+            rr[x][2] = pfma(4.0f, s, p);
+            rr[x][3] = pfma(8.0f, t, q) + m[5];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (HALF == 0) {
+                const f32x2 p = rr[0][j] + rr[1][j], q = psub(rr[0][j], rr[1][j]);
+                A[rp][j] = p + rr[NX - 1][j];
+                B[rp][j] = pfma(0.5f, rr[NX - 1][j], q);
+                s0[rp][j] = pfma(0.25f, rr[NX - 1][j], p);
+                s1[rp][j] = s0[rp][j];
+            } else {
+                A[rp][j] = pfma(0.25f, rr[0][j], rr[1][j]);
+                B[rp][j] = A[rp][j];
+                s0[rp][j] = rr[0][j];
+                s1[rp][j] = pk2(-0.5f) * rr[0][j];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mine4[(2 * j) * 64] = cat2(s0[0][j], s0[1][j]);
+        if (HALF == 1) mine4[(2 * j + 1) * 64] = cat2(s1[0][j], s1[1][j]);
+    }
+}
+
+template <int HALF, bool RELU, class ST>
+__device__ __forceinline__ void wino43m_finish(const f32x2 (&A)[2][4], const f32x2 (&B)[2][4], const float4* theirs, const float4 b4, ST&& store,
+                                               bool live, int row_stride)
+{
+    const f32x2 ba[2] = {(f32x2){b4.x, b4.y}, (f32x2){b4.z, b4.w}};
+    const f32x4* theirs4 = reinterpret_cast<const f32x4*>(theirs);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 g0 = theirs4[(2 * j) * 64];
+        f32x4 g1 = g0;
+        if (HALF == 0) g1 = theirs4[(2 * j + 1) * 64];
+        f32x2 y0[2], y1[2];
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp) {
+            const f32x2 g0p = rp == 0 ? lo2(g0) : hi2(g0), g1p = rp == 0 ? lo2(g1) : hi2(g1);
+            // Y = (P_0 + P_1) + bias: half 0 holds P_0 of its two rows and receives P_1, half 1 holds P_1 of the third row and receives P_0
+            y0[rp] = (HALF == 0 ? A[rp][j] + g0p : g0p + A[rp][j]) + ba[rp];
+            y1[rp] = (B[rp][j] + g1p) + ba[rp];
+            if (RELU) {
+                y0[rp] = (f32x2){y0[rp].x > 0.f ? y0[rp].x : 0.f, y0[rp].y > 0.f ? y0[rp].y : 0.f};
+                y1[rp] = (f32x2){y1[rp].x > 0.f ? y1[rp].x : 0.f, y1[rp].y > 0.f ? y1[rp].y : 0.f};
+            }
+        }
+        if (live) {
+            store(j * 16, cat2(y0[0], y0[1]));
+            if (HALF == 0) store(row_stride + j * 16, cat2(y1[0], y1[1]));
+        }
+    }
+}
+
 }  // namespace w43

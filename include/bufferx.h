@@ -75,7 +75,7 @@ typedef struct bx_params {
     /* Arithmetic forms of the three stages that have more than one (no reference counterpart: the reference leaves the summation order
      * of its convolutions to cuDNN / ATen).  Every form has its own restatement in the oracle (oracle/oracle.py takes the same
      * names) and is bit-exact against it; the value in force is echoed in bx_result.arith_forms.  0 = the default of each. */
-    int32_t desc_conv_form;               /* Cylindrical_Net: BX_DESC_CONV_WINOGRAD43 (F(4x4,3x3), all 8 layers) | _WINOGRAD22 (F(2x2,3x3),
+    int32_t desc_conv_form;               /* Cylindrical_Net: BX_DESC_CONV_WINOGRAD43 (F(4x4,3x3), all 8 layers) | _WINOGRAD43M (mixed F(4x4) / F(3x4) tiles) | _WINOGRAD22 (F(2x2,3x3),
                                            * the 6 layers with >= 64 output channels) | _DIRECT (fp32 fmaf chain chunk > tap > channel) */
     int32_t pose_conv_form;               /* CostNet layers 1..5: BX_POSE_CONV_WINOGRAD43 (valid F(4x4,3x3)) | _WINOGRAD22 (valid F(2x2,3x3)) |
                                            * _DIRECT */
@@ -85,6 +85,8 @@ typedef struct bx_params {
 #define BX_DESC_CONV_WINOGRAD43 0
 #define BX_DESC_CONV_WINOGRAD22 1
 #define BX_DESC_CONV_DIRECT 2
+#define BX_DESC_CONV_WINOGRAD43M 3   /* mixed tiles (round 6): F(4x4,3x3) on the output rows 0..3, F(3x4,3x3) on the rows 4..6 -- the all-F(4x4)
+                                      * form's phantom 8th output row is never multiplied (-8 % MFMAs); own restatement bxo_conv_wino43m */
 #define BX_POSE_CONV_WINOGRAD43 0
 #define BX_POSE_CONV_WINOGRAD22 1
 #define BX_POSE_CONV_DIRECT 2

@@ -186,6 +186,19 @@ def conv_wino43(x, W, bias, relu, ele_n=7, azi_n=20):
     return out
 
 
+def conv_wino43m(x, W, bias, relu, ele_n=7, azi_n=20):
+    """Cylindrical 3x3 layer in the MIXED-tile Winograd form (bxo_conv_wino43m): F(4x4, 3x3) on the output rows 0..3 (bit-identical to
+    conv_wino43 there), F(3x4, 3x3) on the rows 4..6.  Arguments as conv_wino43."""
+    x, W, bias = _f(x), _f(W), _f(bias)
+    units, n_chunks, p_in, _ = x.shape
+    cout = W.shape[-1]
+    assert p_in == ele_n * azi_n and azi_n % 4 == 0 and ele_n == 7 and W.shape == (n_chunks, 9, 16, cout)
+    out = np.zeros((units, (cout + 15) // 16, p_in, 16), np.float32)
+    lib().bxo_conv_wino43m(_p(x), C.c_int(units), C.c_int(n_chunks), C.c_int(ele_n), C.c_int(azi_n), _p(W), _p(bias), C.c_int(cout),
+                           C.c_int(int(relu)), _p(out))
+    return out
+
+
 def conv_wino_valid(x, W, bias, relu, D, fold):
     """CostNet layer as a valid Winograd F(2x2, 3x3) convolution over a D x D map (bxo_conv_wino_valid); fold = 3 for the k(3,3,3)
     layer (its three k rows become input channels), 1 for the k(3,1,3) layers.  x [units][n_chunks][D*fold*D][16]."""
@@ -230,12 +243,14 @@ def pose_conv(layer, x, tap, dims, W, bias, relu, form=None):
 
 def desc_conv(x, tap, W, bias, relu, form=None):
     """One Cylindrical_Net layer in the arithmetic form `form` of bx_params.desc_conv_form: "winograd43" = bxo_conv_wino43 for every
-    layer (k_wino43.hip), "winograd22" = bxo_conv_wino for the layers with >= 64 output channels (k_wino.hip; the two 32-channel layers
+    layer (k_wino43.hip), "winograd43m" = bxo_conv_wino43m (mixed F(4x4) / F(3x4) tiles, k_wino43m.hip), "winograd22" = bxo_conv_wino for the layers with >= 64 output channels (k_wino.hip; the two 32-channel layers
     stay direct), "direct" = fmaf chain over chunk > tap > channel (conv_kernel, k_conv.hip)."""
     form = form or _default_form("desc_conv")
-    assert form in ("winograd43", "winograd22", "direct"), form
+    assert form in ("winograd43", "winograd22", "direct", "winograd43m"), form
     if form == "winograd43":
         return conv_wino43(x, W, bias, relu)
+    if form == "winograd43m":      # mixed tiles: F(4x4) rows 0..3, F(3x4) rows 4..6 (k_wino43m.hip), every layer
+        return conv_wino43m(x, W, bias, relu)
     if form == "winograd22" and np.asarray(W).shape[-1] >= 64:
         return conv_wino(x, W, bias, relu)
     return conv(x, tap, W, bias, relu)

@@ -56,7 +56,7 @@ def test_arith_forms_table():
     from bufferx_amd import lib, config
     hdr = open(os.path.join(ROOT, "include", "bufferx.h")).read()
     for macro, key, name in (("BX_DESC_CONV_WINOGRAD43", "desc_conv", "winograd43"), ("BX_DESC_CONV_WINOGRAD22", "desc_conv", "winograd22"),
-                             ("BX_DESC_CONV_DIRECT", "desc_conv", "direct"), ("BX_POSE_CONV_WINOGRAD22", "pose_conv", "winograd22"),
+                             ("BX_DESC_CONV_DIRECT", "desc_conv", "direct"), ("BX_DESC_CONV_WINOGRAD43M", "desc_conv", "winograd43m"), ("BX_POSE_CONV_WINOGRAD22", "pose_conv", "winograd22"),
                              ("BX_POSE_CONV_DIRECT", "pose_conv", "direct"), ("BX_POSE_CONV_WINOGRAD43", "pose_conv", "winograd43"), ("BX_COST_L0_COLLAPSED", "cost_l0", "collapsed"),
                              ("BX_COST_L0_DIRECT", "cost_l0", "direct")):
         v = int(re.search(r"#define %s (\d+)" % macro, hdr).group(1))

@@ -265,9 +265,9 @@ def test_pose_conv_layer_exact(ctx, oracle, bx, packed, layer):
     assert np.array_equal(lib.chunked_to_logical(_np(out)), ref)
 
 
-@pytest.mark.parametrize("form", ["winograd43", "winograd22", "direct"])
+@pytest.mark.parametrize("form", ["winograd43", "winograd22", "direct", "winograd43m"])
 def test_desc_conv_every_form(oracle, bx, packed, form):
-    """bx_params.desc_conv_form: each of the three forms of the Cylindrical_Net layers against ITS restatement, all 8 layers chained
+    """bx_params.desc_conv_form: each of the four forms of the Cylindrical_Net layers against ITS restatement, all 8 layers chained
     (13 units: ragged last group of the three-unit F(4x4) kernel and of the two-unit F(2x2) kernel), and the form echoed by the context."""
     from bufferx_amd import lib
     cfg = _cfg(bx, K=64, P=64, S=1, nk=64)
@@ -282,6 +282,30 @@ def test_desc_conv_every_form(oracle, bx, packed, form):
             assert np.array_equal(lib.chunked_to_logical(_np(out)), ref), (form, layer)
             x = ref
         assert c.params.desc_conv_form == bx.config.ARITH_FORMS["desc_conv"].index(form)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("units", [1, 2, 3, 4, 7, 16, 17, 33, 100])
+def test_desc_conv_mixed_tiles_unit_counts(oracle, bx, packed, units):
+    """winograd43m (round 6: F(4x4) tiles on the map rows 0..3, F(3x4) tiles on the rows 4..6): items of 16 column blocks = 3.2 units, so
+    every unit count here ends in a different ragged item (1 unit = 5 of 16 blocks ... 100 units = 500 blocks = 31 items + 4 blocks); all
+    eight layers on the GPU's own chained input, bit for bit against bxo_conv_wino43m -- and the rows 0..3 bit for bit against the
+    all-F(4x4) form's restatement (they are the same tiles)."""
+    from bufferx_amd import lib
+    cfg = _cfg(bx, K=max(units, 8), P=64, S=1, nk=8)
+    cfg.arith.desc_conv = "winograd43m"
+    c = lib.Context(cfg, max_points=4096, device=0, packed_weights=packed)
+    try:
+        rng = np.random.default_rng(400 + units)
+        x = np.abs(rng.standard_normal((units, 3, 140, 16))).astype(np.float32)
+        for layer, L in enumerate(packed["desc"]):
+            ref = oracle.desc_conv(x, bx.weights.cyl_tap_table(), L["W"], L["b"], L["relu"], form="winograd43m")
+            out = lib.chunked_to_logical(_np(c.conv_layer(0, layer, lib.logical_to_chunked(x), ref.shape)))
+            assert np.array_equal(out, ref), (units, layer, np.argwhere(out != ref)[:4])
+            r43 = oracle.desc_conv(x, bx.weights.cyl_tap_table(), L["W"], L["b"], L["relu"], form="winograd43")
+            assert np.array_equal(out.reshape(units, -1, 7, 20, 16)[:, :, :4], r43.reshape(units, -1, 7, 20, 16)[:, :, :4])
+            x = ref
     finally:
         c.close()
 

@@ -186,6 +186,28 @@ def test_winograd43_layers_close_to_direct_form(oracle, bx, packed):
         assert np.abs(oracle.conv(x, tap, L["W"], L["b"], True) - oracle.conv_wino43(x, L["W"], L["b"], True)).max() < 2e-5
 
 
+def test_mixed_tile_winograd_layers(oracle, bx, packed):
+    """bxo_conv_wino43m (round 6, the contract of k_wino43m.hip): the map rows 0..3 are the F(4x4, 3x3) tiles of bxo_conv_wino43 BIT FOR BIT;
+    the rows 4..6 are F(3x4, 3x3) tiles (F(3, 3) on the points {1, -1, 1/2, -1/2, inf}) and agree with the direct form to the same bound
+    as the all-F(4x4) form; unit impulses at the positions that touch the seam between the two tile rows, the elevation padding and the
+    azimuth wrap-around."""
+    rng = np.random.default_rng(0)
+    tap = bx.weights.cyl_tap_table()
+    x = np.abs(rng.standard_normal((4, 3, 140, 16))).astype(np.float32)
+    for L in packed["desc"]:
+        a = oracle.conv(x, tap, L["W"], L["b"], L["relu"])
+        b = oracle.conv_wino43(x, L["W"], L["b"], L["relu"])
+        m = oracle.conv_wino43m(x, L["W"], L["b"], L["relu"])
+        assert np.array_equal(m.reshape(4, -1, 7, 20, 16)[:, :, :4], b.reshape(4, -1, 7, 20, 16)[:, :, :4])
+        assert a.shape == m.shape and np.abs(a - m).max() < 1e-4 * max(1.0, float(np.abs(a).max()) / 5.0)
+        x = a
+    L = packed["desc"][1]
+    for p in (60, 63, 79, 80, 99, 100, 119, 120, 123, 139):      # rows 3..6: the seam, the last row, both wrap-around columns
+        x = np.zeros((1, 4, 140, 16), np.float32)
+        x[0, :, p, :] = 1.0
+        assert np.abs(oracle.conv(x, tap, L["W"], L["b"], True) - oracle.conv_wino43m(x, L["W"], L["b"], True)).max() < 2e-5
+
+
 def test_valid_winograd43_layers_close_to_direct_form(oracle, bx, packed):
     """bxo_conv_wino43_valid (valid F(4x4, 3x3), the contract of k_wino43v.hip and the default form of CostNet layers 1..5) against bxo_conv
     and against the F(2x2) form: D = 18 (folded k rows), 16 and 12 (last tiles reach beyond the map: zero rows / dropped outputs), 14, 10;

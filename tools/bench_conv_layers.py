@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--K", type=int, default=5000)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--tag", default="")
+    ap.add_argument("--form", default=None, help="cfg.arith.desc_conv (default: the library default)")
     args = ap.parse_args()
     import torch
     import bufferx_amd as bx
@@ -27,6 +28,8 @@ def main():
     cfg = bx.make_cfg("3DMatch")
     cfg.patch.num_fps, cfg.patch.num_points_per_patch, cfg.patch.num_scales = args.K, 64, 1
     cfg.patch.search_radius_thresholds = [5]
+    if args.form:
+        cfg.arith.desc_conv = args.form
     pw = bx.weights.fold_and_pack(bx.weights.synthetic_state_dict(0))
     ctx = lib.Context(cfg, max_points=4096, device=0, packed_weights=pw)
     K = args.K
@@ -54,6 +57,7 @@ def main():
     res["stack_us"] = round(sum(res.values()), 1)
     res["wino_us"] = round(sum(v for k, v in res.items() if k[:2] in ("L0", "L1", "L2", "L3", "L4", "L5")), 1)
     res["tag"] = args.tag
+    res["form"] = args.form or "default"
     if os.environ.get("BX_W43_STAMPS"):
         buf = (C.c_int64 * 512)()
         ctx.lib.bx_debug_read(ctx.handle, buf, 512)

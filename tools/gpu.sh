@@ -50,7 +50,9 @@ for step in "$@"; do
     layers)
       tag=${arg%%,*}; so=""; [[ "$arg" == *,* ]] && so=${arg#*,}
       tag=${tag:-shipped}
-      if [ -n "$so" ]; then BX_HIP_SO=$PWD/buffer-x_amd/csrc/$so timeout 600 python tools/bench_conv_layers.py --tag $tag 2>&1 | tail -3 | tee -a $OUT/layers.jsonl
+      # SO = variants/lib...so (a variant library) or form=NAME (cfg.arith.desc_conv of the shipped library)
+      if [[ "$so" == form=* ]]; then timeout 600 python tools/bench_conv_layers.py --tag $tag --form ${so#form=} 2>&1 | tail -3 | tee -a $OUT/layers.jsonl
+      elif [ -n "$so" ]; then BX_HIP_SO=$PWD/buffer-x_amd/csrc/$so timeout 600 python tools/bench_conv_layers.py --tag $tag 2>&1 | tail -3 | tee -a $OUT/layers.jsonl
       else timeout 600 python tools/bench_conv_layers.py --tag $tag 2>&1 | tail -3 | tee -a $OUT/layers.jsonl; fi;;
     stage)
       w=${arg%%,*}; rest=""; [[ "$arg" == *,* ]] && rest=$(echo "${arg#*,}" | tr ',' ' ')

@@ -105,7 +105,7 @@ def file_flags(src):
 
 def main():
     bad = 0
-    for src in ("k_wino43.hip", "k_wino43v.hip"):
+    for src in ("k_wino43.hip", "k_wino43v.hip", "k_wino43m.hip"):
         with tempfile.TemporaryDirectory() as td:
             out = os.path.join(td, "k.s")
             subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + file_flags(src) + ["-o", out, os.path.join(CS, src)], check=True, stderr=subprocess.DEVNULL)
