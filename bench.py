@@ -469,6 +469,10 @@ def main():
                        "avg_launch_ms": round(stage_ms, 4), "launches": ng_n, "algorithmic_bytes_per_launch": nbytes,
                        "grid_build_ms_per_pair": round(gb_ms / max(gb_n, 1), 4),
                        "query_kernel_avg_ms": round(ng_ms / ng_n, 4), "query_kernel_frac": round(kach / PEAK_HBM_GBS, 4),
+                       # beside the SURVEY 8(d) fraction: the same on the bytes the query kernel really MOVES (PMC; the counted hand-over
+                       # writes only the real slots of a patch, and no index list)
+                       "query_kernel_frac_on_moved_bytes": (round(pmc_ball["ball_query_bytes_per_launch"] / (ng_ms / ng_n * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+                                                            if fresh(pmc_ball) and pmc_ball.get("ball_query_bytes_per_launch") else None),
                        "note": "stage time per (cloud, scale) call = (grid build of the pair + its query kernels) / calls; the index list "
                                "(4KP of the algorithmic bytes) is not written by the whole-pair path: nothing reads it"}
         out = {
