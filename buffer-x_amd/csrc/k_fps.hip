@@ -45,9 +45,9 @@ namespace {
 constexpr int FPS_THREADS = 1024;
 constexpr int FPS_WAVES = FPS_THREADS / 64;
 constexpr int FPS_MAX_G = 64;            // 64 workgroups x 16 384 points = 1 048 576 points per cloud (the neighbour bitmap's limit too)
-constexpr int FPS_REC = 64;              // 8-byte words per exchange record: the bound's two {epoch, value} granules, then K x five {key hi, key lo, x, y, z}
-constexpr int FPS_K = 12;                // most candidates a workgroup publishes per round (2 + 5 K <= FPS_REC; fewer when G x K would exceed the resolving wave's 64 lanes)
-constexpr int FPS_TMAX = 8;              // samples one round may resolve
+constexpr int FPS_REC = 64;              // 8-byte words per exchange record: the bound's two {epoch, value} granules, then K x seven {key hi, key lo, x, y, z, second key hi, lo}
+constexpr int FPS_K = 8;                 // most candidates a workgroup publishes per round (2 + 7 K <= FPS_REC; fewer when G x K would exceed the resolving wave's 64 lanes)
+constexpr int FPS_TMAX = 16;             // samples one round may resolve
 constexpr int FPS_NE = 2 * FPS_WAVES;    // entries of a workgroup: the two largest keys of each of its 16 buckets
 constexpr long long FPS_IDK = (long long)0x8000000000000000LL;    // identity of the key maximum
 constexpr int FPS_MAX_CLOUDS = 2;
@@ -312,14 +312,16 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
     // Rounds 1-5 resolved ONE sample per cross-workgroup exchange: K strictly dependent iterations of (scan -> workgroup reduce ->
     // publish -> L2 round trip -> reduce over G -> decode) = 1.95 us each, none of it shortened by skipped work (profiles/r05_fps.txt).
     // A round now resolves SEVERAL samples from one exchange, exactly:
-    //   * every bucket (wave) keeps its TWO largest keys; a workgroup publishes the K largest of its 32 bucket entries with their
-    //     coordinates, plus a BOUND: a key that every point of the workgroup outside the published list stays below (the largest
-    //     unlisted entry, or a listed second-largest -- the rest of that bucket is below it);
+    //   * every bucket (wave) keeps its TWO largest keys; a workgroup publishes its K largest bucket MAXIMA (the candidates) with their
+    //     coordinates and, per candidate, the bucket's second key -- every other point of that bucket is below it --, plus a BOUND for the
+    //     buckets it does not list: its (K + 1)-th largest bucket maximum;
     //   * every workgroup then runs the same deterministic resolution on the same G x K candidates (one per lane of wave 0): take the
     //     largest key -> that is the next sample (the global arg-max: keys are unique, every workgroup's maximum is listed); apply it to
-    //     the CANDIDATES (td = min(td, d), the very operations of the scan); the next largest candidate key is the next sample as long
-    //     as it is >= the largest bound B -- running min-distances only fall, so no unlisted point can have overtaken it; stop at
-    //     the first candidate below B (or FPS_TMAX samples) and exchange again;
+    //     the CANDIDATES (td = min(td, d), the very operations of the scan); raise the bound B to the second key of the sampled
+    //     candidate's bucket (its other points are no longer covered by a listed maximum); the next largest candidate key is the next
+    //     sample as long as it is >= B -- running min-distances only fall, and the hidden points of a bucket whose maximum is still an
+    //     untouched candidate are below that candidate; a candidate whose key a sample LOWERED hands its bucket's second key to B as
+    //     well --; stop at the first candidate below B or after FPS_TMAX samples, and exchange again;
     //   * the next round starts by applying the resolved samples to the buckets they can change (box test per sample, one lane each).
     // The sample sequence is the sequential one bit for bit (every FPS test, tilings and tie lattices included); what changes is the
     // number of exchanges: ~1 per 4-6 samples.
@@ -449,10 +451,10 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                 else { cxv = s_exyz[par][lane][0]; cyv = s_exyz[par][lane][1]; czv = s_exyz[par][lane][2]; }
             }
             static_assert(FPS_WAVES == 16, "row reductions over the sixteen bucket entries");
-            const long long e2max = row_max_key(ek2);      // lanes >= 16 hold the identity
             bool fail = false;
+            long long ce2 = ek2;                           // second key of the candidate's bucket
             if (G == 1) {
-                bk = e2max;                                // one workgroup: all sixteen bucket maxima are candidates
+                bk = FPS_IDK;                              // one workgroup: all sixteen bucket maxima are candidates, nothing is unlisted
             } else {
                 // ---- publish the K largest candidates + the bound.  Rank of every bucket maximum among the sixteen by all-pairs comparison
                 //      (keys broadcast from LDS: independent compares instead of K + 1 dependent DPP reductions on the one wave every other
@@ -481,15 +483,17 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                 }
                 if (act && rank < K) {
                     const unsigned long long eh = (unsigned long long)ep << 32;
-                    unsigned long long* d = my + 2 + rank * 5;
+                    unsigned long long* d = my + 2 + rank * 7;
                     granule_store(d + 0, eh | (unsigned)((unsigned long long)ck >> 32), fast);
                     granule_store(d + 1, eh | (unsigned)((unsigned long long)ck & 0xffffffffu), fast);
                     granule_store(d + 2, eh | __float_as_uint(cxv), fast);
                     granule_store(d + 3, eh | __float_as_uint(cyv), fast);
                     granule_store(d + 4, eh | __float_as_uint(czv), fast);
+                    granule_store(d + 5, eh | (unsigned)((unsigned long long)ek2 >> 32), fast);
+                    granule_store(d + 6, eh | (unsigned)((unsigned long long)ek2 & 0xffffffffu), fast);
                 }
-                // bound: the largest bucket maximum that is not listed (rank K), or the largest second key
-                long long bnd = e2max;
+                // bound for the buckets that are not listed: the largest of their maxima (rank K)
+                long long bnd = FPS_IDK;
                 {
                     const unsigned long long mk = __ballot(act && rank == K);
                     if (mk != 0ULL) {
@@ -506,9 +510,9 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                 FPS_TR(3);
                 // ---- poll: lane (workgroup cw, entry ce) reads its candidate's five granules + the two of the workgroup's bound
                 act = lane < G * K;
-                unsigned long long r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, b0 = 0, b1 = 0;
+                unsigned long long r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, b0 = 0, b1 = 0;
                 {
-                    unsigned long long* rp = slots + ((size_t)par * FPS_MAX_G + (act ? cw : 0)) * FPS_REC + 2 + (act ? ce : 0) * 5;
+                    unsigned long long* rp = slots + ((size_t)par * FPS_MAX_G + (act ? cw : 0)) * FPS_REC + 2 + (act ? ce : 0) * 7;
                     unsigned long long* bp = slots + ((size_t)par * FPS_MAX_G + (act ? cw : 0)) * FPS_REC;
                     unsigned spins = 0;
                     while (true) {
@@ -516,26 +520,31 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                         if (act) {
                             if (fast) {
                                 asm volatile("buffer_inv sc1\n\t"
-                                             "global_load_dwordx2 %0, %7, off\n\t"
-                                             "global_load_dwordx2 %1, %7, off offset:8\n\t"
-                                             "global_load_dwordx2 %2, %7, off offset:16\n\t"
-                                             "global_load_dwordx2 %3, %7, off offset:24\n\t"
-                                             "global_load_dwordx2 %4, %7, off offset:32\n\t"
-                                             "global_load_dwordx2 %5, %8, off\n\t"
-                                             "global_load_dwordx2 %6, %8, off offset:8\n\t"
+                                             "global_load_dwordx2 %0, %9, off\n\t"
+                                             "global_load_dwordx2 %1, %9, off offset:8\n\t"
+                                             "global_load_dwordx2 %2, %9, off offset:16\n\t"
+                                             "global_load_dwordx2 %3, %9, off offset:24\n\t"
+                                             "global_load_dwordx2 %4, %9, off offset:32\n\t"
+                                             "global_load_dwordx2 %5, %9, off offset:40\n\t"
+                                             "global_load_dwordx2 %6, %9, off offset:48\n\t"
+                                             "global_load_dwordx2 %7, %10, off\n\t"
+                                             "global_load_dwordx2 %8, %10, off offset:8\n\t"
                                              "s_waitcnt vmcnt(0)"
-                                             : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(b0), "=&v"(b1) : "v"(rp), "v"(bp) : "memory");
+                                             : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(b0), "=&v"(b1) : "v"(rp), "v"(bp) : "memory");
                             } else {
                                 r0 = __hip_atomic_load(rp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 r1 = __hip_atomic_load(rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 r2 = __hip_atomic_load(rp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 r3 = __hip_atomic_load(rp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 r4 = __hip_atomic_load(rp + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                r5 = __hip_atomic_load(rp + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                r6 = __hip_atomic_load(rp + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 b0 = __hip_atomic_load(bp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 b1 = __hip_atomic_load(bp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             }
                             ok = (unsigned)(r0 >> 32) == ep && (unsigned)(r1 >> 32) == ep && (unsigned)(r2 >> 32) == ep &&
-                                 (unsigned)(r3 >> 32) == ep && (unsigned)(r4 >> 32) == ep && (unsigned)(b0 >> 32) == ep && (unsigned)(b1 >> 32) == ep;
+                                 (unsigned)(r3 >> 32) == ep && (unsigned)(r4 >> 32) == ep && (unsigned)(r5 >> 32) == ep && (unsigned)(r6 >> 32) == ep &&
+                                 (unsigned)(b0 >> 32) == ep && (unsigned)(b1 >> 32) == ep;
                         }
                         if (__all(ok)) break;
                         if (++spins > FPS_SPIN_LIMIT) { fail = true; break; }
@@ -545,11 +554,12 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                 if (fail && lane == 0) atomicOr(a.err_flag, 1);
                 ck = act ? (long long)(((unsigned long long)(unsigned)r0 << 32) | (unsigned)r1) : FPS_IDK;
                 bk = act ? (long long)(((unsigned long long)(unsigned)b0 << 32) | (unsigned)b1) : FPS_IDK;
+                ce2 = act ? (long long)(((unsigned long long)(unsigned)r5 << 32) | (unsigned)r6) : FPS_IDK;
                 cxv = __uint_as_float((unsigned)r2); cyv = __uint_as_float((unsigned)r3); czv = __uint_as_float((unsigned)r4);
             }
             FPS_TR(4);
             // ---- resolution: the same inputs and the same operations in every workgroup
-            const long long B = G == 1 ? e2max : wave_max_key(bk);
+            long long B = G == 1 ? FPS_IDK : wave_max_key(bk);        // bound of everything that is not a candidate
             int tlim = a.m - j;
             tlim = tlim < FPS_TMAX ? tlim : FPS_TMAX;
             int tc = 0;
@@ -570,13 +580,28 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                 const float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(czv), wl));
                 if (lane == 0) { s_pkey[par][tc] = bestk; s_pick[par][tc] = make_float4(qx, qy, qz, 0.f); }
                 ++tc;
+                // the sampled candidate's bucket: its other points are bounded by the bucket's second key from now on
+                {
+                    const long long e2w = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)ce2 >> 32), wl) << 32) |
+                                                      (unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)ce2 & 0xffffffffu), wl));
+                    B = e2w > B ? e2w : B;
+                }
                 // the sample against the candidates: the operations of the bucket update above
+                bool lowered;
                 {
                     float dx = cxv - qx, dy = cyv - qy, dz = czv - qz;
                     float d = (dx * dx + dy * dy) + dz * dz;
                     // (a lane without a candidate holds the identity key: its high word is -0.0f, which min() keeps)
-                    const float nt = fminf(d, __int_as_float((int)(ck >> 32)));
+                    const float otd = __int_as_float((int)(ck >> 32));
+                    const float nt = fminf(d, otd);
+                    lowered = act && lane != wl && __float_as_int(nt) != __float_as_int(otd);
                     ck = (long long)(((unsigned long long)(unsigned)__float_as_int(nt) << 32) | ((unsigned long long)ck & 0xffffffffULL));
+                }
+                // another candidate lost distance: the hidden points of ITS bucket are no longer covered by a listed maximum either -- the
+                // bucket's second key joins the bound (one more reduction, only in the rounds where it happens)
+                if (__any(lowered)) {
+                    const long long e2l = wave_max_key(lowered ? ce2 : FPS_IDK);
+                    B = e2l > B ? e2l : B;
                 }
             }
             if (lane == 0) s_npick[par] = tc;
@@ -787,7 +812,7 @@ int bxk_fps_range(bx_ctx* c, hipStream_t s, const float* const* xyz, const int* 
         const char* ep = getenv("BX_FPS_PRUNE");       // test / measurement hook: 0 = scan every bucket in every iteration
         a.prune = ep ? atoi(ep) : 1;
         const char* ek = getenv("BX_FPS_K");          // measurement hook: candidates per workgroup and round (results do not depend on it)
-        a.kmax = ek ? atoi(ek) : 4;
+        a.kmax = ek ? atoi(ek) : 8;
         if (a.kmax < 1) a.kmax = 1;
         if (a.kmax > FPS_K) a.kmax = FPS_K;
         // a cloud beyond the context's max_points (stage entry point only: bx_register_pair checks its clouds) has no room for its order:
