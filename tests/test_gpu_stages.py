@@ -68,6 +68,38 @@ def test_fps_protocols_and_tilings(ctx, oracle, monkeypatch, colocate, ppt, prun
     assert np.array_equal(_np(kp), xyz[ref])
 
 
+@pytest.mark.parametrize("k", ["1", "2", "4", "8"])
+@pytest.mark.parametrize("case", ["blobs", "duplicates", "lattice", "line", "tiny"])
+def test_fps_batched_rounds(ctx, oracle, monkeypatch, k, case):
+    """Round 6: a cross-workgroup exchange resolves SEVERAL samples (K candidates per workgroup with their buckets' second keys, a bound
+    for everything unlisted; k_fps.hip).  The sample sequence must be the sequential one whatever the candidate count (BX_FPS_K: 1 = one
+    sample per exchange, as rounds 1-5) on clouds built to stress the resolution: dense blobs (the largest running distances cluster, a
+    sample lowers several other candidates), exact duplicates spread over buckets (keys that differ in the tie-break word only), an
+    integer lattice (distance ties everywhere), points on a line (Morton buckets degenerate) and a cloud smaller than one bucket."""
+    monkeypatch.setenv("BX_FPS_K", k)
+    rng = np.random.default_rng(60 + len(case))
+    if case == "blobs":
+        c = rng.random((12, 3), np.float32) * 6
+        xyz = np.concatenate([c[i] + rng.standard_normal((3000, 3)).astype(np.float32) * 0.05 for i in range(12)] + [rng.random((400, 3), np.float32) * 6])
+    elif case == "duplicates":
+        base = rng.random((5000, 3), np.float32) * 3
+        xyz = np.concatenate([base, base[rng.permutation(5000)[:3000]], base[:2000], rng.random((10000, 3), np.float32) * 3])
+    elif case == "lattice":
+        g = np.stack(np.meshgrid(np.arange(30), np.arange(30), np.arange(24), indexing="ij"), -1).reshape(-1, 3).astype(np.float32) * 0.125
+        xyz = g
+    elif case == "line":
+        t = rng.random(30000).astype(np.float32)
+        xyz = np.stack([t * 8, t * 0.5 + 1, np.full_like(t, 2.0)], 1)
+    else:
+        xyz = rng.random((37, 3), np.float32) + 1
+    xyz = np.ascontiguousarray(xyz[rng.permutation(len(xyz))], np.float32)
+    m = min(400, len(xyz))
+    idx, kp = ctx.fps(xyz, m)
+    ref = oracle.fps(xyz, m)
+    assert np.array_equal(_np(idx), ref), (case, k, int(np.argmax(_np(idx) != ref)))
+    assert np.array_equal(_np(kp), xyz[ref])
+
+
 def test_fps_beyond_one_xcd(bx, oracle, packed):
     """More than 32 workgroups per cloud cannot share one XCD: dispatch-order placement, agent-scope protocol (600k points)."""
     from bufferx_amd import lib
