@@ -21,13 +21,14 @@ void bx_set_error(const char* fmt, ...)
 
 namespace {
 
-struct ProfEvt { hipEvent_t a, b; int tag; };
+struct ProfEvt { hipEvent_t a, b; int tag; int weight; };      // weight: launches the bracket stands for (2: both clouds of a scale in one convolution stack)
 struct ProfScope {
     bx_ctx* c; hipStream_t s; ProfEvt e; bool on;
-    ProfScope(bx_ctx* c_, hipStream_t s_, int tag) : c(c_), s(s_), on(c_->prof_on != 0)
+    ProfScope(bx_ctx* c_, hipStream_t s_, int tag, int weight = 1) : c(c_), s(s_), on(c_->prof_on != 0)
     {
         if (!on) return;
         e.tag = tag;
+        e.weight = weight;
         if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) { on = false; return; }
         (void)hipEventRecord(e.a, s);
     }
@@ -76,6 +77,7 @@ void bx_prof_mark(bx_ctx* c, hipStream_t s, int tag, int begin)
     static thread_local ProfEvt cur;
     if (begin) {
         cur.tag = tag;
+        cur.weight = 1;
         if (hipEventCreate(&cur.a) != hipSuccess || hipEventCreate(&cur.b) != hipSuccess) { cur.tag = -1; return; }
         (void)hipEventRecord(cur.a, s);
     } else if (cur.tag == tag) {
@@ -108,12 +110,14 @@ void carve(bx_ctx* c, char* base, size_t* total)
     const size_t NMAX = (size_t)c->p.max_points;
     const size_t SK = S * K;
     Carver cv{base, 0};
-    const size_t act = K * 2 * 972 * 16;  // largest map: CostNet layer-0 output; Desc 128-channel maps are K*8*140*16
+    // largest map: CostNet layer-0 output (K x 2 x 972 x 16) or the 128-channel Desc maps of BOTH clouds of a scale (2 K x 8 x 140 x 16:
+    // the whole-pair path runs the two clouds' stacks as one launch per layer -- round 6)
+    const size_t act = std::max(K * 2 * 972 * 16, 2 * K * 8 * BX_EA * 16);
     c->act0 = cv.take<float>(act);
     c->act1 = cv.take<float>(act);
     c->patches = cv.take<float>(K * P * 3);
     c->pcnt = cv.take<int32_t>(K);
-    c->feat = cv.take<float>(K * BX_RAD * BX_EA * 16);
+    c->feat = cv.take<float>(2 * K * BX_RAD * BX_EA * 16);      // both clouds of a scale
     c->pts_perm = cv.take<float>(NMAX * 3);
     for (int i = 0; i < 2; ++i) {
         c->fps_idx[i] = cv.take<int32_t>(KM);
@@ -355,6 +359,24 @@ int desc_stack(bx_ctx* c, hipStream_t s, const float* feat, int K, float* desc, 
     return bxk_desc_head(c, s, in, K, desc, equi);
 }
 
+// both clouds of a scale as ONE stack of 2 K units (round 6): a unit's arithmetic does not depend on what shares its launch, so the
+// descriptors are those of two K-unit stacks bit for bit; one pair alone pays 13 instead of 2 x 7 persistent rounds on the 64-column
+// layers (25 instead of 2 x 13 on the 128-column ones).  feat [2 K][3][140][16], heads per cloud.
+int desc_stack_pair(bx_ctx* c, hipStream_t s, const float* feat, int K, float* const* desc, float* const* equi)
+{
+    const float* in = feat;
+    float* bufs[2] = {c->act0, c->act1};
+    int rc;
+    for (int l = 0; l < BX_NDESC; ++l) {
+        float* out = bufs[l & 1];
+        if ((rc = bxk_conv(c, s, 0, l, in, nullptr, 2 * K, out)) != BX_OK) return rc;
+        in = out;
+    }
+    for (int cl = 0; cl < 2; ++cl)
+        if ((rc = bxk_desc_head(c, s, in + (size_t)cl * K * 2 * BX_EA * 16, K, desc[cl], equi[cl])) != BX_OK) return rc;
+    return BX_OK;
+}
+
 int pose_stack(bx_ctx* c, hipStream_t s, const float* s_equi, const float* t_equi, const int32_t* s_mids, const int32_t* t_mids,
                const int32_t* m_dev, int max_m, float* ind, float* logits_out)
 {
@@ -392,6 +414,8 @@ static int create_impl(bx_ctx* c, int device_id)
         c->conv_persist = (!e || atoi(e) != 0) ? 1 : 0;
         e = getenv("BX_CONV_PERSIST_CAP");
         c->conv_cap_override = e ? atoi(e) : 0;
+        e = getenv("BX_DESC_BATCH");                 // measurement hook: 0 = one Cylindrical_Net stack per cloud (rounds 1-5); results do not depend on it
+        c->desc_batch = (!e || atoi(e) != 0) ? 1 : 0;
         e = getenv("BX_RAD_SLICES");                 // measurement hook (k_radius.hip); results do not depend on it
         c->rad_slices = e ? atoi(e) : 0;
         // arithmetic forms: bx_params (validated by bx_create), never the environment
@@ -585,7 +609,7 @@ int bx_profile_read(bx_ctx* c, double* ms_out, int32_t* count_out)
     auto* v = static_cast<std::vector<ProfEvt>*>(c->prof);
     for (auto& e : *v) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess && e.tag >= 0 && e.tag < BX_PROF_TAGS) { ms_out[e.tag] += ms; count_out[e.tag] += 1; }
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess && e.tag >= 0 && e.tag < BX_PROF_TAGS) { ms_out[e.tag] += ms; count_out[e.tag] += e.weight; }
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
@@ -1023,7 +1047,16 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
             if ((rc = bxk_ball_grids(c, s, clouds, ns, perms, 2, st->des_r, S, p.search_radius_thresholds, 1, S - 1)) != BX_OK) return rc;
             if ((rc = bxk_ball_rows(c, s, c->kpts, 2, S, 0, K, 1, S - 1)) != BX_OK) return rc;
         }
-        if (!multi || (early && i > 0)) {
+        if (!multi && c->desc_batch && !(c->cap_on && c->cap.scale == i)) {
+            // throughput form: neighbour gather + patch features per cloud, then BOTH clouds' Cylindrical_Net stacks as one launch per layer
+            for (int cl = 0; cl < 2; ++cl) {
+                c->ball_waves_hint = p.search_radius_thresholds[i] >= 1.5 ? 4 : 2;
+                { ProfScope ps(c, s, 2); if ((rc = bxk_ball_query(c, s, cl * S + i, ns[cl], c->kpts[cl], 0, K, &st->des_r[i], P, nullptr, c->patches, c->pcnt)) != BX_OK) return rc; }
+                { ProfScope ps(c, s, 3); if ((rc = bxk_patch_features(c, s, c->patches, K, P, &st->des_r[i], aligned_z, c->R_sc[i][cl], c->feat + (size_t)cl * K * BX_RAD * BX_EA * 16, c->pcnt, c->kpts[cl])) != BX_OK) return rc; }
+            }
+            LaneScope ls(c, s, 2); ProfScope ps(c, s, 4, 2);
+            if ((rc = desc_stack_pair(c, s, c->feat, K, c->desc_sc[i], c->equi_sc[i])) != BX_OK) return rc;
+        } else if (!multi || (early && i > 0)) {
             if ((rc = tgt_go()) != BX_OK) return rc;
             for (int cl = 0; cl < 2; ++cl)
                 if ((rc = describe(i, cl, 0, K)) != BX_OK) return rc;

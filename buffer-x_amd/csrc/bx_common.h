@@ -191,6 +191,7 @@ struct bx_ctx {
     int use_wino_pose;                  // bx_params.pose_conv_form: 1 = winograd (valid F(2x2, 3x3), k_wino.hip), 2 = winograd43 (valid F(4x4, 3x3), k_wino43v.hip), 0 = direct -- CostNet layers 1..5
     int use_wino;                       // bx_params.desc_conv_form: 3 = winograd43m (mixed F(4x4) / F(3x4) tiles, every layer; fragments in Wwino43), 2 = winograd43 (F(4x4, 3x3), every layer), 1 = winograd22 (F(2x2, 3x3), layers with >= 64 output channels), 0 = direct
     int conv_persist, conv_cap_override, n_cu;
+    int desc_batch;                     // 1 (default): both clouds of a scale in one Cylindrical_Net stack (bx_api.hip::desc_stack_pair); hook BX_DESC_BATCH
     int rad_slices;                     // measurement hook BX_RAD_SLICES: point slices of radius_hist_kernel (0 = the default, 16)
     double *d_cost_wp, *d_cost_wq;      // collapsed CostNet layer 0 (k_cost.hip): binary64 weights of the P / Q convolutions
     int cost_direct;                    // bx_params.cost_l0_form == direct: layer 0 as the fp32 MFMA convolution of the implicit volume (cost_l1_kernel)
