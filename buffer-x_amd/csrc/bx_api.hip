@@ -1047,7 +1047,9 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
             if ((rc = bxk_ball_grids(c, s, clouds, ns, perms, 2, st->des_r, S, p.search_radius_thresholds, 1, S - 1)) != BX_OK) return rc;
             if ((rc = bxk_ball_rows(c, s, c->kpts, 2, S, 0, K, 1, S - 1)) != BX_OK) return rc;
         }
-        if (!multi && c->desc_batch && !(c->cap_on && c->cap.scale == i)) {
+        // (2 K units must still fit the 32-bit byte offsets of the F(4x4) kernels: beyond ~14 900 keypoints the clouds run one by one)
+        const bool batch_fits = (long long)2 * K * 8 * BX_EA * 64 < 0x7fffffffLL - (1LL << 24);
+        if (!multi && c->desc_batch && batch_fits && !(c->cap_on && c->cap.scale == i)) {
             // throughput form: neighbour gather + patch features per cloud, then BOTH clouds' Cylindrical_Net stacks as one launch per layer
             for (int cl = 0; cl < 2; ++cl) {
                 c->ball_waves_hint = p.search_radius_thresholds[i] >= 1.5 ? 4 : 2;
