@@ -388,14 +388,17 @@ def main():
         stale_note = lambda d: None if d is None else ("%s (%s)" % (d["_file"], "measured on these kernel sources" if not d["_stale"] else "STALE: the kernel sources changed since that profile, value withheld"))
         # --- dominant kernel: Desc conv stack (8 MFMA launches per cloud per scale)
         conv_ms, conv_n = stages.get("desc_conv", (0.0, 0))
-        flops_per_stack = 2.0 * DESC_CONV_MMAC_PER_PATCH * 1e6 * K
+        # units of one stack launch: the throughput form of the whole-pair call runs BOTH clouds of a scale as one stack of 2 K units
+        # (round 6, bx_api.hip::desc_stack_pair; BX_DESC_BATCH=0 is the measurement hook for one cloud per stack)
+        KU = K * (2 if os.environ.get("BX_DESC_BATCH", "1") != "0" and args.keypoint_tiles <= 1 else 1)
+        flops_per_stack = 2.0 * DESC_CONV_MMAC_PER_PATCH * 1e6 * KU
         roof = None
         if conv_n:
             conv_n = max(1, int(round(conv_n * ran)))
             ach = flops_per_stack / (conv_ms / conv_n * 1e-3) / 1e12
             form = forms["desc_conv"]
             ex_mmac = DESC_EXECUTED_MMAC_PER_PATCH[form]
-            ex_ach = 2.0 * ex_mmac * 1e6 * K / (conv_ms / conv_n * 1e-3) / 1e12
+            ex_ach = 2.0 * ex_mmac * 1e6 * KU / (conv_ms / conv_n * 1e-3) / 1e12
             roof = {"kernel": {"winograd43": "wino43_kernel<...> x8 (Winograd F(4x4,3x3), items of 32 tile rows; every layer)",
                                "winograd43m": "wino43m_kernel<...> x8 (mixed Winograd tiles: F(4x4,3x3) rows 0..3 + F(3x4,3x3) rows 4..6, items of 16 column blocks; every layer)",
                                "winograd22": "wino_pair_kernel<...> x6 (Winograd F(2x2,3x3), two units per workgroup) + conv_kernel<...> x2",
@@ -404,14 +407,14 @@ def main():
                     # the roofline statement: flops ISSUED on the matrix pipe / time / peak (<= 1 by construction)
                     "achieved": round(ex_ach, 3), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ex_ach / PEAK_F32_MATRIX_TFLOPS, 4),
-                    "executed_flops_per_launch": 2.0 * ex_mmac * 1e6 * K,
+                    "executed_flops_per_launch": 2.0 * ex_mmac * 1e6 * KU, "units_per_launch": KU,
                     # the algorithm-adjusted rate: what the reference's convolution multiplies (59.35 MMAC per patch) over
                     # the same time; exceeds the peak when a Winograd form issues fewer multiplications -- NOT a roofline fraction
                     "algorithmic_flops_per_launch": flops_per_stack, "algorithmic_rate_tflops": round(ach, 3),
                     "algorithmic_rate_x_peak": round(ach / PEAK_F32_MATRIX_TFLOPS, 4),
                     "issued_over_direct_macs": round(ex_mmac / DESC_CONV_MMAC_PER_PATCH, 4),
                     "traffic": pmc["desc_conv_stack_bytes_per_launch"] if fresh(pmc) else None,
-                    "traffic_note": "HBM bytes per stack launch, rocprofv3 PMC: %s; algorithmic in+out maps = 3.27e9" % stale_note(pmc),
+                    "traffic_note": "HBM bytes per stack launch, rocprofv3 PMC: %s; algorithmic in+out maps = %.3g" % (stale_note(pmc), 3.27e9 * KU / 5000.0),
                     "mfma_busy": busy.get("desc_conv_stack") if fresh(busy) else None,
                     "mfma_busy_note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), time-weighted over the 8 layers: %s" % stale_note(busy),
                     "avg_launch_ms": round(conv_ms / conv_n, 4), "launches": conv_n,

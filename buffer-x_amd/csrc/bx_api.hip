@@ -1056,7 +1056,7 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
                 { ProfScope ps(c, s, 2); if ((rc = bxk_ball_query(c, s, cl * S + i, ns[cl], c->kpts[cl], 0, K, &st->des_r[i], P, nullptr, c->patches, c->pcnt)) != BX_OK) return rc; }
                 { ProfScope ps(c, s, 3); if ((rc = bxk_patch_features(c, s, c->patches, K, P, &st->des_r[i], aligned_z, c->R_sc[i][cl], c->feat + (size_t)cl * K * BX_RAD * BX_EA * 16, c->pcnt, c->kpts[cl])) != BX_OK) return rc; }
             }
-            LaneScope ls(c, s, 2); ProfScope ps(c, s, 4, 2);
+            LaneScope ls(c, s, 2); ProfScope ps(c, s, 4);      // ONE bracket = one launch sequence of 2 K units (bench.py prices it as such)
             if ((rc = desc_stack_pair(c, s, c->feat, K, c->desc_sc[i], c->equi_sc[i])) != BX_OK) return rc;
         } else if (!multi || (early && i > 0)) {
             if ((rc = tgt_go()) != BX_OK) return rc;
