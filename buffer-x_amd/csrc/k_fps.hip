@@ -437,76 +437,44 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
         FPS_TR(1);
         __syncthreads();
         FPS_TR(2);
+        if (G > 1) {
+            // ---- publish, DISTRIBUTED over the sixteen waves (the first form ranked the bucket maxima on wave 0 alone: ~180 dependent
+            //      instructions = 1 800 cycles per round on the one wave every other wave waits for).  A wave knows its own bucket maximum;
+            //      its rank among the sixteen = the maxima that beat it (equal keys -- identities, padding -- ordered by wave index): one LDS
+            //      read, one compare, one ballot.  Rank < K: the wave stores its candidate's seven granules itself; rank K: its key is the
+            //      bound of everything the workgroup does not list.
+            const long long other = lane < FPS_WAVES ? s_ekey[par][lane] : FPS_IDK;
+            const bool beats = lane < FPS_WAVES && (other > e1k || (other == e1k && lane < wave));
+            const int rank = __popcll(__ballot(beats));
+            unsigned long long* my = slots + ((size_t)par * FPS_MAX_G + g) * FPS_REC;
+            const unsigned long long eh = (unsigned long long)ep << 32;
+            if (rank < K) {
+                if (lane < 7) {
+                    const unsigned v = lane == 0 ? (unsigned)((unsigned long long)e1k >> 32)
+                                     : lane == 1 ? (unsigned)((unsigned long long)e1k & 0xffffffffu)
+                                     : lane == 2 ? __float_as_uint(e1x) : lane == 3 ? __float_as_uint(e1y) : lane == 4 ? __float_as_uint(e1z)
+                                     : lane == 5 ? (unsigned)((unsigned long long)e2k >> 32) : (unsigned)((unsigned long long)e2k & 0xffffffffu);
+                    granule_store(my + 2 + rank * 7 + lane, eh | v, fast);
+                }
+            } else if (rank == K) {
+                if (lane < 2) granule_store(my + lane, eh | (lane == 0 ? (unsigned)((unsigned long long)e1k >> 32) : (unsigned)((unsigned long long)e1k & 0xffffffffu)), fast);
+            }
+        }
         if (wave == 0) {
-            // lanes 0..15: the largest key of every bucket = the workgroup's candidates; lanes 16..31: the buckets' second largest keys --
-            // everything else in bucket v is below its second key, so their maximum bounds every point that is not a candidate
             long long ck = FPS_IDK, bk = FPS_IDK;          // candidate key / bound of the candidate's workgroup (resolution inputs)
+            long long ce2 = FPS_IDK;                       // second key of the candidate's bucket
             float cxv = 0.f, cyv = 0.f, czv = 0.f;
             bool act = lane < FPS_WAVES;
-            long long ek2 = FPS_IDK;
-            if (act) {
-                ck = s_ekey[par][lane];
-                ek2 = s_ekey[par][FPS_WAVES + lane];
-                if (LDSXYZ) { const int sl = s_eslot[par][lane]; cxv = s_pts[sl]; cyv = s_pts[NP + sl]; czv = s_pts[2 * NP + sl]; }
-                else { cxv = s_exyz[par][lane][0]; cyv = s_exyz[par][lane][1]; czv = s_exyz[par][lane][2]; }
-            }
-            static_assert(FPS_WAVES == 16, "row reductions over the sixteen bucket entries");
             bool fail = false;
-            long long ce2 = ek2;                           // second key of the candidate's bucket
             if (G == 1) {
-                bk = FPS_IDK;                              // one workgroup: all sixteen bucket maxima are candidates, nothing is unlisted
+                // one workgroup: all sixteen bucket maxima are candidates (straight from LDS), nothing is unlisted
+                if (act) {
+                    ck = s_ekey[par][lane];
+                    ce2 = s_ekey[par][FPS_WAVES + lane];
+                    if (LDSXYZ) { const int sl = s_eslot[par][lane]; cxv = s_pts[sl]; cyv = s_pts[NP + sl]; czv = s_pts[2 * NP + sl]; }
+                    else { cxv = s_exyz[par][lane][0]; cyv = s_exyz[par][lane][1]; czv = s_exyz[par][lane][2]; }
+                }
             } else {
-                // ---- publish the K largest candidates + the bound.  Rank of every bucket maximum among the sixteen by all-pairs comparison
-                //      (keys broadcast from LDS: independent compares instead of K + 1 dependent DPP reductions on the one wave every other
-                //      wave is waiting for); equal keys (identities, padding) are ordered by lane so that ranks are unique
-                unsigned long long* my = slots + ((size_t)par * FPS_MAX_G + g) * FPS_REC;
-                // fast path on the keys' high words (the fp32 distances): a tie among them that reaches the published ranks takes the exact
-                // 64-bit pass (tie lattices; identities and padding keys tie, but far below rank K)
-                int rank = 0;
-                {
-                    const int h = (int)(ck >> 32);
-                    int eq = 0;
-#pragma unroll
-                    for (int q = 0; q < FPS_WAVES; ++q) {
-                        const int hq = (int)(s_ekey[par][q] >> 32);
-                        rank += hq > h ? 1 : 0;
-                        eq += hq == h ? 1 : 0;
-                    }
-                    if (__any(act && eq > 1 && rank <= K)) {
-                        rank = 0;
-#pragma unroll 1
-                        for (int q = 0; q < FPS_WAVES; ++q) {
-                            const long long kq = s_ekey[par][q];
-                            rank += (kq > ck || (kq == ck && q < lane)) ? 1 : 0;
-                        }
-                    }
-                }
-                if (act && rank < K) {
-                    const unsigned long long eh = (unsigned long long)ep << 32;
-                    unsigned long long* d = my + 2 + rank * 7;
-                    granule_store(d + 0, eh | (unsigned)((unsigned long long)ck >> 32), fast);
-                    granule_store(d + 1, eh | (unsigned)((unsigned long long)ck & 0xffffffffu), fast);
-                    granule_store(d + 2, eh | __float_as_uint(cxv), fast);
-                    granule_store(d + 3, eh | __float_as_uint(cyv), fast);
-                    granule_store(d + 4, eh | __float_as_uint(czv), fast);
-                    granule_store(d + 5, eh | (unsigned)((unsigned long long)ek2 >> 32), fast);
-                    granule_store(d + 6, eh | (unsigned)((unsigned long long)ek2 & 0xffffffffu), fast);
-                }
-                // bound for the buckets that are not listed: the largest of their maxima (rank K)
-                long long bnd = FPS_IDK;
-                {
-                    const unsigned long long mk = __ballot(act && rank == K);
-                    if (mk != 0ULL) {
-                        const int l = __ffsll((long long)mk) - 1;
-                        const long long kl = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)ck >> 32), l) << 32) |
-                                                         (unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)ck & 0xffffffffu), l));
-                        bnd = kl > bnd ? kl : bnd;
-                    }
-                }
-                if (lane < 2) {
-                    const unsigned v = lane == 0 ? (unsigned)((unsigned long long)bnd >> 32) : (unsigned)((unsigned long long)bnd & 0xffffffffu);
-                    granule_store(my + lane, ((unsigned long long)ep << 32) | v, fast);
-                }
                 FPS_TR(3);
                 // ---- poll: lane (workgroup cw, entry ce) reads its candidate's five granules + the two of the workgroup's bound
                 act = lane < G * K;
