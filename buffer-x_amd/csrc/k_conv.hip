@@ -555,6 +555,17 @@ int launch_conv(bx_ctx* c, int net, int layer, hipStream_t s, const ConvLayerDev
 }
 }  // namespace
 
+// units per workgroup of the smallest CostNet layers (6: 8x8 -> 6x6, 7: 6x6 -> 4x4, 8: 4x4 -> 2x2, 9: 2x2 -> 1).  Round 6: 16 / 32 / 128 -> 8 / 8 / 16
+// for layers 7..9: more, smaller workgroups (27.5 / 11.9 / 9.1 -> 17.7 / 7.8 / 6.0 us per launch at 1 400 matches, rocprofv3)
+#ifndef BX_TAIL_G6
+#define BX_TAIL_G6 8
+#endif
+#ifndef BX_TAIL_G7
+#define BX_TAIL_G7 8
+#define BX_TAIL_G8 8
+#define BX_TAIL_G9 16
+#endif
+
 int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, const int32_t* units_dev, int max_units, float* out)
 {
     constexpr int CYL = (BX_ELE + 2) * (BX_AZI + 2);   // 198 LDS rows per unit: cylindrical map + halo
@@ -607,10 +618,10 @@ int bxk_conv(bx_ctx* c, hipStream_t s, int net, int layer, const float* in, cons
             case 3: return launch_conv<4, 9, 196, 196, 144, 128, 2, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
             case 4: return launch_conv<8, 9, 144, 144, 100, 128, 2, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
             case 5: return launch_conv<8, 9, 100, 100, 64, 64, 4, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
-            case 6: return launch_conv<4, 9, 64, 64, 36, 64, 8, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
-            case 7: return launch_conv<4, 9, 36, 36, 16, 32, 16, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
-            case 8: return launch_conv<2, 9, 16, 16, 4, 32, 32, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
-            case 9: return launch_conv<2, 4, 4, 4, 1, 20, 128, false>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
+            case 6: return launch_conv<4, 9, 64, 64, 36, 64, BX_TAIL_G6, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
+            case 7: return launch_conv<4, 9, 36, 36, 16, 32, BX_TAIL_G7, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
+            case 8: return launch_conv<2, 9, 16, 16, 4, 32, BX_TAIL_G8, true>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
+            case 9: return launch_conv<2, 4, 4, 4, 1, 20, BX_TAIL_G9, false>(c, net, layer, s, L, in, units_dev, max_units, out, c->skip);
         }
     }
     bx_set_error("bxk_conv: bad net/layer %d/%d", net, layer);

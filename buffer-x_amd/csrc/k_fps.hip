@@ -45,8 +45,8 @@ namespace {
 constexpr int FPS_THREADS = 1024;
 constexpr int FPS_WAVES = FPS_THREADS / 64;
 constexpr int FPS_MAX_G = 64;            // 64 workgroups x 16 384 points = 1 048 576 points per cloud (the neighbour bitmap's limit too)
-constexpr int FPS_REC = 64;              // 8-byte words per exchange record: the bound's two {epoch, value} granules, then K x seven {key hi, key lo, x, y, z, second key hi, lo}
-constexpr int FPS_K = 8;                 // most candidates a workgroup publishes per round (2 + 7 K <= FPS_REC; fewer when G x K would exceed the resolving wave's 64 lanes)
+constexpr int FPS_REC = 64;              // 8-byte words per exchange record: the bound's {epoch, value} granule, then K x six {key hi, key lo, x, y, z, second key hi}
+constexpr int FPS_K = 8;                 // most candidates a workgroup publishes per round (1 + 6 K <= FPS_REC; fewer when G x K would exceed the resolving wave's 64 lanes)
 constexpr int FPS_TMAX = 16;             // samples one round may resolve
 constexpr int FPS_NE = 2 * FPS_WAVES;    // entries of a workgroup: the two largest keys of each of its 16 buckets
 constexpr long long FPS_IDK = (long long)0x8000000000000000LL;    // identity of the key maximum
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
             // ---- publish, DISTRIBUTED over the sixteen waves (the first form ranked the bucket maxima on wave 0 alone: ~180 dependent
             //      instructions = 1 800 cycles per round on the one wave every other wave waits for).  A wave knows its own bucket maximum;
             //      its rank among the sixteen = the maxima that beat it (equal keys -- identities, padding -- ordered by wave index): one LDS
-            //      read, one compare, one ballot.  Rank < K: the wave stores its candidate's seven granules itself; rank K: its key is the
+            //      read, one compare, one ballot.  Rank < K: the wave stores its candidate's six granules itself; rank K: its distance is the
             //      bound of everything the workgroup does not list.
             const long long other = lane < FPS_WAVES ? s_ekey[par][lane] : FPS_IDK;
             const bool beats = lane < FPS_WAVES && (other > e1k || (other == e1k && lane < wave));
@@ -449,20 +449,22 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
             unsigned long long* my = slots + ((size_t)par * FPS_MAX_G + g) * FPS_REC;
             const unsigned long long eh = (unsigned long long)ep << 32;
             if (rank < K) {
-                if (lane < 7) {
+                // (bounds travel as HIGH WORDS only -- the fp32 distances: the resolution continues only while a candidate's distance is
+                //  strictly ABOVE the bound's, a tie in the distance ends the round -- conservative, hence exact, and half the words)
+                if (lane < 6) {
                     const unsigned v = lane == 0 ? (unsigned)((unsigned long long)e1k >> 32)
                                      : lane == 1 ? (unsigned)((unsigned long long)e1k & 0xffffffffu)
                                      : lane == 2 ? __float_as_uint(e1x) : lane == 3 ? __float_as_uint(e1y) : lane == 4 ? __float_as_uint(e1z)
-                                     : lane == 5 ? (unsigned)((unsigned long long)e2k >> 32) : (unsigned)((unsigned long long)e2k & 0xffffffffu);
-                    granule_store(my + 2 + rank * 7 + lane, eh | v, fast);
+                                     : (unsigned)((unsigned long long)e2k >> 32);
+                    granule_store(my + 1 + rank * 6 + lane, eh | v, fast);
                 }
             } else if (rank == K) {
-                if (lane < 2) granule_store(my + lane, eh | (lane == 0 ? (unsigned)((unsigned long long)e1k >> 32) : (unsigned)((unsigned long long)e1k & 0xffffffffu)), fast);
+                if (lane == 0) granule_store(my, eh | (unsigned)((unsigned long long)e1k >> 32), fast);
             }
         }
         if (wave == 0) {
-            long long ck = FPS_IDK, bk = FPS_IDK;          // candidate key / bound of the candidate's workgroup (resolution inputs)
-            long long ce2 = FPS_IDK;                       // second key of the candidate's bucket
+            long long ck = FPS_IDK;                        // candidate key (resolution input)
+            int bh = (int)0x80000000, ce2h = (int)0x80000000;   // high words: bound of the candidate's workgroup / second key of its bucket
             float cxv = 0.f, cyv = 0.f, czv = 0.f;
             bool act = lane < FPS_WAVES;
             bool fail = false;
@@ -470,17 +472,17 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                 // one workgroup: all sixteen bucket maxima are candidates (straight from LDS), nothing is unlisted
                 if (act) {
                     ck = s_ekey[par][lane];
-                    ce2 = s_ekey[par][FPS_WAVES + lane];
+                    ce2h = (int)(s_ekey[par][FPS_WAVES + lane] >> 32);
                     if (LDSXYZ) { const int sl = s_eslot[par][lane]; cxv = s_pts[sl]; cyv = s_pts[NP + sl]; czv = s_pts[2 * NP + sl]; }
                     else { cxv = s_exyz[par][lane][0]; cyv = s_exyz[par][lane][1]; czv = s_exyz[par][lane][2]; }
                 }
             } else {
                 FPS_TR(3);
-                // ---- poll: lane (workgroup cw, entry ce) reads its candidate's five granules + the two of the workgroup's bound
+                // ---- poll: lane (workgroup cw, entry ce) reads its candidate's six granules + the one of the workgroup's bound
                 act = lane < G * K;
-                unsigned long long r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, b0 = 0, b1 = 0;
+                unsigned long long r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, b0 = 0;
                 {
-                    unsigned long long* rp = slots + ((size_t)par * FPS_MAX_G + (act ? cw : 0)) * FPS_REC + 2 + (act ? ce : 0) * 7;
+                    unsigned long long* rp = slots + ((size_t)par * FPS_MAX_G + (act ? cw : 0)) * FPS_REC + 1 + (act ? ce : 0) * 6;
                     unsigned long long* bp = slots + ((size_t)par * FPS_MAX_G + (act ? cw : 0)) * FPS_REC;
                     unsigned spins = 0;
                     while (true) {
@@ -488,17 +490,15 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                         if (act) {
                             if (fast) {
                                 asm volatile("buffer_inv sc1\n\t"
-                                             "global_load_dwordx2 %0, %9, off\n\t"
-                                             "global_load_dwordx2 %1, %9, off offset:8\n\t"
-                                             "global_load_dwordx2 %2, %9, off offset:16\n\t"
-                                             "global_load_dwordx2 %3, %9, off offset:24\n\t"
-                                             "global_load_dwordx2 %4, %9, off offset:32\n\t"
-                                             "global_load_dwordx2 %5, %9, off offset:40\n\t"
-                                             "global_load_dwordx2 %6, %9, off offset:48\n\t"
-                                             "global_load_dwordx2 %7, %10, off\n\t"
-                                             "global_load_dwordx2 %8, %10, off offset:8\n\t"
+                                             "global_load_dwordx2 %0, %7, off\n\t"
+                                             "global_load_dwordx2 %1, %7, off offset:8\n\t"
+                                             "global_load_dwordx2 %2, %7, off offset:16\n\t"
+                                             "global_load_dwordx2 %3, %7, off offset:24\n\t"
+                                             "global_load_dwordx2 %4, %7, off offset:32\n\t"
+                                             "global_load_dwordx2 %5, %7, off offset:40\n\t"
+                                             "global_load_dwordx2 %6, %8, off\n\t"
                                              "s_waitcnt vmcnt(0)"
-                                             : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(b0), "=&v"(b1) : "v"(rp), "v"(bp) : "memory");
+                                             : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(b0) : "v"(rp), "v"(bp) : "memory");
                             } else {
                                 r0 = __hip_atomic_load(rp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 r1 = __hip_atomic_load(rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -506,13 +506,10 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                                 r3 = __hip_atomic_load(rp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 r4 = __hip_atomic_load(rp + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 r5 = __hip_atomic_load(rp + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                r6 = __hip_atomic_load(rp + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 b0 = __hip_atomic_load(bp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                b1 = __hip_atomic_load(bp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             }
                             ok = (unsigned)(r0 >> 32) == ep && (unsigned)(r1 >> 32) == ep && (unsigned)(r2 >> 32) == ep &&
-                                 (unsigned)(r3 >> 32) == ep && (unsigned)(r4 >> 32) == ep && (unsigned)(r5 >> 32) == ep && (unsigned)(r6 >> 32) == ep &&
-                                 (unsigned)(b0 >> 32) == ep && (unsigned)(b1 >> 32) == ep;
+                                 (unsigned)(r3 >> 32) == ep && (unsigned)(r4 >> 32) == ep && (unsigned)(r5 >> 32) == ep && (unsigned)(b0 >> 32) == ep;
                         }
                         if (__all(ok)) break;
                         if (++spins > FPS_SPIN_LIMIT) { fail = true; break; }
@@ -521,13 +518,13 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                 }
                 if (fail && lane == 0) atomicOr(a.err_flag, 1);
                 ck = act ? (long long)(((unsigned long long)(unsigned)r0 << 32) | (unsigned)r1) : FPS_IDK;
-                bk = act ? (long long)(((unsigned long long)(unsigned)b0 << 32) | (unsigned)b1) : FPS_IDK;
-                ce2 = act ? (long long)(((unsigned long long)(unsigned)r5 << 32) | (unsigned)r6) : FPS_IDK;
+                bh = act ? (int)(unsigned)b0 : (int)0x80000000;
+                ce2h = act ? (int)(unsigned)r5 : (int)0x80000000;
                 cxv = __uint_as_float((unsigned)r2); cyv = __uint_as_float((unsigned)r3); czv = __uint_as_float((unsigned)r4);
             }
             FPS_TR(4);
             // ---- resolution: the same inputs and the same operations in every workgroup
-            long long B = G == 1 ? FPS_IDK : wave_max_key(bk);        // bound of everything that is not a candidate
+            int Bh = G == 1 ? (int)0x80000000 : wave_max_i32(bh);     // bound (fp32 distance bits) of everything that is not a candidate
             int tlim = a.m - j;
             tlim = tlim < FPS_TMAX ? tlim : FPS_TMAX;
             int tc = 0;
@@ -541,7 +538,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                     }
                     break;
                 }
-                if (tc > 0 && bestk < B) break;                  // a point outside the lists may have a larger key: exchange again
+                if (tc > 0 && (int)(bestk >> 32) <= Bh) break;   // a point outside the lists may have a larger (or the same) distance: exchange again
                 const int wl = __ffsll((long long)__ballot(act && ck == bestk)) - 1;
                 const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cxv), wl));
                 const float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cyv), wl));
@@ -550,9 +547,8 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                 ++tc;
                 // the sampled candidate's bucket: its other points are bounded by the bucket's second key from now on
                 {
-                    const long long e2w = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)ce2 >> 32), wl) << 32) |
-                                                      (unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)ce2 & 0xffffffffu), wl));
-                    B = e2w > B ? e2w : B;
+                    const int e2w = __builtin_amdgcn_readlane(ce2h, wl);
+                    Bh = e2w > Bh ? e2w : Bh;
                 }
                 // the sample against the candidates: the operations of the bucket update above
                 bool lowered;
@@ -568,8 +564,8 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                 // another candidate lost distance: the hidden points of ITS bucket are no longer covered by a listed maximum either -- the
                 // bucket's second key joins the bound (one more reduction, only in the rounds where it happens)
                 if (__any(lowered)) {
-                    const long long e2l = wave_max_key(lowered ? ce2 : FPS_IDK);
-                    B = e2l > B ? e2l : B;
+                    const int e2l = wave_max_i32(lowered ? ce2h : (int)0x80000000);
+                    Bh = e2l > Bh ? e2l : Bh;
                 }
             }
             if (lane == 0) s_npick[par] = tc;
