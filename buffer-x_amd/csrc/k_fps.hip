@@ -93,6 +93,19 @@ __device__ __forceinline__ int wave_max_i32(int v)
     o = __builtin_amdgcn_update_dpp(id, v, 0x143, 0xc, 0xf, false); v = o > v ? o : v;   // row_bcast:31
     return __builtin_amdgcn_readlane(v, 63);
 }
+// two independent maxima in one pass: the DPP steps of one chain fill the dependent-issue bubbles of the other
+__device__ __forceinline__ void wave_max2_i32(int a, int b, int& ma, int& mb)
+{
+    const int id = (int)0x80000000;
+    int o, p;
+#define BX_STEP2(ctl, rm) \
+    o = __builtin_amdgcn_update_dpp(id, a, ctl, rm, 0xf, false); p = __builtin_amdgcn_update_dpp(id, b, ctl, rm, 0xf, false); \
+    a = o > a ? o : a; b = p > b ? p : b;
+    BX_STEP2(0x111, 0xf) BX_STEP2(0x112, 0xf) BX_STEP2(0x114, 0xf) BX_STEP2(0x118, 0xf) BX_STEP2(0x142, 0xa) BX_STEP2(0x143, 0xc)
+#undef BX_STEP2
+    ma = __builtin_amdgcn_readlane(a, 63);
+    mb = __builtin_amdgcn_readlane(b, 63);
+}
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v)
 {
     unsigned o;
@@ -523,50 +536,75 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                 cxv = __uint_as_float((unsigned)r2); cyv = __uint_as_float((unsigned)r3); czv = __uint_as_float((unsigned)r4);
             }
             FPS_TR(4);
-            // ---- resolution: the same inputs and the same operations in every workgroup
+            // ---- resolution: the same inputs and the same operations in every workgroup.  This loop is the serial instruction stream of ONE
+            //      wave with fifteen parked at the barrier, ~10 cycles per dependent instruction: it is written for instruction count.  The
+            //      keys stay split in their words; the second keys of the candidates a sample lowered wait in a per-lane maximum (`pend`)
+            //      whose reduction rides in the bubbles of the NEXT iteration's key reduction (two independent DPP chains) and reaches the
+            //      bound before that iteration's test -- exactly when the one-reduction-more of the first form applied it; a sample is kept
+            //      in lane t of five registers (one compare, five selects) and stored once after the loop instead of behind an exec-mask branch per sample.
             int Bh = G == 1 ? (int)0x80000000 : wave_max_i32(bh);     // bound (fp32 distance bits) of everything that is not a candidate
             int tlim = a.m - j;
             tlim = tlim < FPS_TMAX ? tlim : FPS_TMAX;
             int tc = 0;
-            while (tc < tlim) {
-                const long long bestk = wave_max_key(ck);
-                if (bestk < 0) {
-                    // no candidate anywhere (every point within 1e-3 of the origin, or sampled): upstream yields index 0 -- once per round
-                    if (tc == 0) {
-                        if (lane == 0) { s_pkey[par][0] = bestk; s_pick[par][0] = make_float4(xyz[0], xyz[1], xyz[2], 0.f); }
-                        tc = 1;
-                    }
-                    break;
+            int khi = (int)(ck >> 32);
+            const unsigned klo = (unsigned)((unsigned long long)ck & 0xffffffffu);
+            int pend = (int)0x80000000;
+            int pkh = 0, pkl = 0, pkx = 0, pky = 0, pkz = 0;           // lane t: the round's sample t (key words, coordinates)
+            // (tlim >= 1: the first iteration can only leave through "no candidate", every later one through the bound or the count)
+            for (;;) {
+                int mh, pb;
+                wave_max2_i32(khi, pend, mh, pb);
+                Bh = __builtin_amdgcn_readfirstlane(pb > Bh ? pb : Bh);
+                // no candidate anywhere (every point within 1e-3 of the origin, or sampled: upstream yields index 0 -- once per round), or a
+                // point outside the lists may have a larger (or the same) distance: exchange again
+                if (mh < 0 || (tc > 0 && mh <= Bh)) break;
+                // one lane holds the largest distance almost always: its low word is the answer; ties go through a second reduction
+                const unsigned long long bal = __ballot(khi == mh);
+                int wl = __builtin_ctzll(bal);
+                unsigned ml = (unsigned)__builtin_amdgcn_readlane((int)klo, wl);
+                if (__builtin_expect(__popcll(bal) != 1, 0)) {
+                    ml = wave_max_u32(khi == mh ? klo : 0u);
+                    wl = __builtin_ctzll(__ballot(khi == mh && klo == ml));
                 }
-                if (tc > 0 && (int)(bestk >> 32) <= Bh) break;   // a point outside the lists may have a larger (or the same) distance: exchange again
-                const int wl = __ffsll((long long)__ballot(act && ck == bestk)) - 1;
-                const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cxv), wl));
-                const float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cyv), wl));
-                const float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(czv), wl));
-                if (lane == 0) { s_pkey[par][tc] = bestk; s_pick[par][tc] = make_float4(qx, qy, qz, 0.f); }
+                const int qxi = __builtin_amdgcn_readlane(__float_as_int(cxv), wl);
+                const int qyi = __builtin_amdgcn_readlane(__float_as_int(cyv), wl);
+                const int qzi = __builtin_amdgcn_readlane(__float_as_int(czv), wl);
+                const int e2w = __builtin_amdgcn_readlane(ce2h, wl);
+                // lane tc of the five sample registers, in place (v_writelane ignores the exec mask; the lane select travels in m0, which
+                // does not count against the one-SGPR limit of the encoding)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"     // m0 is reserved but unused by this kernel (tests/test_isa_lint.py checks)
+                asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                             "v_writelane_b32 %0, %6, m0\n\tv_writelane_b32 %1, %7, m0\n\tv_writelane_b32 %2, %8, m0\n\t"
+                             "v_writelane_b32 %3, %9, m0\n\tv_writelane_b32 %4, %10, m0"
+                             : "+v"(pkh), "+v"(pkl), "+v"(pkx), "+v"(pky), "+v"(pkz)
+                             : "s"(tc), "s"(mh), "s"((int)ml), "s"(qxi), "s"(qyi), "s"(qzi) : "m0");
+#pragma clang diagnostic pop
                 ++tc;
                 // the sampled candidate's bucket: its other points are bounded by the bucket's second key from now on
-                {
-                    const int e2w = __builtin_amdgcn_readlane(ce2h, wl);
-                    Bh = e2w > Bh ? e2w : Bh;
-                }
+                Bh = __builtin_amdgcn_readfirstlane(e2w > Bh ? e2w : Bh);
                 // the sample against the candidates: the operations of the bucket update above
-                bool lowered;
                 {
+                    const float qx = __int_as_float(qxi), qy = __int_as_float(qyi), qz = __int_as_float(qzi);
                     float dx = cxv - qx, dy = cyv - qy, dz = czv - qz;
                     float d = (dx * dx + dy * dy) + dz * dz;
                     // (a lane without a candidate holds the identity key: its high word is -0.0f, which min() keeps)
-                    const float otd = __int_as_float((int)(ck >> 32));
-                    const float nt = fminf(d, otd);
-                    lowered = act && lane != wl && __float_as_int(nt) != __float_as_int(otd);
-                    ck = (long long)(((unsigned long long)(unsigned)__float_as_int(nt) << 32) | ((unsigned long long)ck & 0xffffffffULL));
+                    const float nt = fminf(d, __int_as_float(khi));
+                    // another candidate lost distance: the hidden points of ITS bucket are no longer covered by a listed maximum either -- the
+                    // bucket's second key joins the bound (through `pend`, before the next test)
+                    const bool lowered = act && lane != wl && __float_as_int(nt) != khi;
+                    khi = __float_as_int(nt);
+                    pend = lowered && ce2h > pend ? ce2h : pend;
                 }
-                // another candidate lost distance: the hidden points of ITS bucket are no longer covered by a listed maximum either -- the
-                // bucket's second key joins the bound (one more reduction, only in the rounds where it happens)
-                if (__any(lowered)) {
-                    const int e2l = wave_max_i32(lowered ? ce2h : (int)0x80000000);
-                    Bh = e2l > Bh ? e2l : Bh;
-                }
+                if (tc >= tlim) break;
+            }
+            const bool none = tc == 0;
+            if (none) {
+                if (lane == 0) { s_pkey[par][0] = -1LL; s_pick[par][0] = make_float4(xyz[0], xyz[1], xyz[2], 0.f); }
+                tc = 1;
+            } else if (lane < tc) {
+                s_pkey[par][lane] = (long long)(((unsigned long long)(unsigned)pkh << 32) | (unsigned)pkl);
+                s_pick[par][lane] = make_float4(__int_as_float(pkx), __int_as_float(pky), __int_as_float(pkz), 0.f);
             }
             if (lane == 0) s_npick[par] = tc;
             FPS_TR(5);
