@@ -344,6 +344,27 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
     __syncthreads();
     int j = a.j0 > 0 ? a.j0 : 1;                     // next output index
     int lastpar = 1;
+    int npv = 1;                                     // samples of the previous round (the "round" in front of the first: the first sample)
+    int outn = 0, outj = 0;                          // samples of the previous round that still have to be written, their first output index
+    // the samples of a round are written to global memory by wave 1 of workgroup 0 DURING the next round's resolution (the wave would be parked at
+    // the barrier): ~400 cycles per round off the path every workgroup waits on.  s_pkey / s_pick of a parity are stable until the round after next.
+    auto emit = [&](int pp, int cnt, int jb) {
+        if (g == 0 && wave == 1 && lane < cnt) {
+            const long long fk = s_pkey[pp][lane];
+            int old = 0;
+            if (fk >= 0) {
+                const unsigned tbw = ~(unsigned)((unsigned long long)fk & 0xffffffffu);
+                old = (int)(((tbw & 0x7fffffu) << lt) | (tbw >> 23));
+            }
+            const float4 q = s_pick[pp][lane];
+            a.idx_out[cloud][jb + lane] = old;
+            if (a.kpts_out[cloud]) {
+                a.kpts_out[cloud][(size_t)(jb + lane) * 3 + 0] = q.x;
+                a.kpts_out[cloud][(size_t)(jb + lane) * 3 + 1] = q.y;
+                a.kpts_out[cloud][(size_t)(jb + lane) * 3 + 2] = q.z;
+            }
+        }
+    };
     for (unsigned r = 0; j < a.m; ++r) {
         const int par = (int)(r & 1u), prv = par ^ 1;
         lastpar = par;
@@ -355,7 +376,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
         // ---- A: the samples of the previous round against this bucket.  Box test of every sample at once (lane q = sample q):
         //      d2(sample, box) from the same rounded operations as the point distances (monotone: <= the computed distance of every
         //      point inside the box), so a sample with d2 >= the bucket's largest running min-distance cannot change the bucket
-        const int np = s_npick[prv];
+        const int np = npv;
         unsigned long long hit;
         {
             bool h = false;
@@ -475,6 +496,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
                 if (lane == 0) granule_store(my, eh | (unsigned)((unsigned long long)e1k >> 32), fast);
             }
         }
+        emit(prv, outn, outj);
         if (wave == 0) {
             long long ck = FPS_IDK;                        // candidate key (resolution input)
             int bh = (int)0x80000000, ce2h = (int)0x80000000;   // high words: bound of the candidate's workgroup / second key of its bucket
@@ -542,13 +564,14 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
             //      whose reduction rides in the bubbles of the NEXT iteration's key reduction (two independent DPP chains) and reaches the
             //      bound before that iteration's test -- exactly when the one-reduction-more of the first form applied it; a sample is kept
             //      in lane t of five registers (one compare, five selects) and stored once after the loop instead of behind an exec-mask branch per sample.
-            int Bh = G == 1 ? (int)0x80000000 : wave_max_i32(bh);     // bound (fp32 distance bits) of everything that is not a candidate
+            int Bh = (int)0x80000000;      // bound (fp32 distance bits) of everything that is not a candidate: the workgroups' bounds reach it
+                                           // through `pend` in the first iteration, whose sample (the global maximum) needs no bound
             int tlim = a.m - j;
             tlim = tlim < FPS_TMAX ? tlim : FPS_TMAX;
             int tc = 0;
             int khi = (int)(ck >> 32);
             const unsigned klo = (unsigned)((unsigned long long)ck & 0xffffffffu);
-            int pend = (int)0x80000000;
+            int pend = bh;
             int pkh = 0, pkl = 0, pkx = 0, pky = 0, pkz = 0;           // lane t: the round's sample t (key words, coordinates)
             // (tlim >= 1: the first iteration can only leave through "no candidate", every later one through the bound or the count)
             for (;;) {
@@ -613,23 +636,10 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
         FPS_TR(6);
         const int npk = s_npick[par];
         if (tr) tdp[7] = npk;
-        if (g == 0 && t < npk) {
-            const long long fk = s_pkey[par][t];
-            int old = 0;
-            if (fk >= 0) {
-                const unsigned tbw = ~(unsigned)((unsigned long long)fk & 0xffffffffu);
-                old = (int)(((tbw & 0x7fffffu) << lt) | (tbw >> 23));
-            }
-            const float4 q = s_pick[par][t];
-            a.idx_out[cloud][j + t] = old;
-            if (a.kpts_out[cloud]) {
-                a.kpts_out[cloud][(size_t)(j + t) * 3 + 0] = q.x;
-                a.kpts_out[cloud][(size_t)(j + t) * 3 + 1] = q.y;
-                a.kpts_out[cloud][(size_t)(j + t) * 3 + 2] = q.z;
-            }
-        }
+        npv = npk; outn = npk; outj = j;
         j += npk;
     }
+    emit(lastpar, outn, outj);
 #undef FPS_TR
     // the samples of the last round have not been applied to the buckets yet: a following launch of a tiled run picks the running
     // min-distances up from td_state and applies only the LAST keypoint itself (min is idempotent: applying that one twice is harmless)
