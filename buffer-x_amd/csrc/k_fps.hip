@@ -378,12 +378,14 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
         //      point inside the box), so a sample with d2 >= the bucket's largest running min-distance cannot change the bucket
         const int np = npv;
         unsigned long long hit;
+        float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);      // lane q: sample q of the previous round (the update below takes it from here)
         {
             bool h = false;
             if (lane < np) {
                 h = true;
+                qv = s_pick[prv][lane];
                 if (a.prune && scanned) {
-                    const float4 q = s_pick[prv][lane];
+                    const float4 q = qv;
                     const float ex = fmaxf(fmaxf(lox - q.x, q.x - hix), 0.0f), ey = fmaxf(fmaxf(loy - q.y, q.y - hiy), 0.0f), ez = fmaxf(fmaxf(loz - q.z, q.z - hiz), 0.0f);
                     const float db = (ex * ex + ey * ey) + ez * ez;
                     h = db < wmax;
@@ -397,7 +399,10 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(FpsArgs a)
         while (hit != 0ULL) {
             const int q = __ffsll((long long)hit) - 1;
             hit &= hit - 1ULL;
-            const float4 c4 = s_pick[prv][q];
+            float4 c4;                                    // (a lane broadcast instead of a second LDS read with its latency in the chain)
+            c4.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv.x), q));
+            c4.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv.y), q));
+            c4.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv.z), q));
 #pragma unroll
             for (int i = 0; i < PPT; ++i) {
                 float dx = px[i] - c4.x, dy = py[i] - c4.y, dz = pz[i] - c4.z;
