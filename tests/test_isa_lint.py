@@ -23,4 +23,7 @@ def test_isa_lint_clean():
         # (the mixed-tile kernel carries two specialised copies of its plane loop: 144 + 120 MFMAs)
         assert r["mfma"] == (264 if "wino43m" in r["kernel"] else 144) and r["vmcnt0_inside_plane_loop"] == 0, r
         assert r["scratch_in_plane_loop"] == 0, r
+    # k_fps.hip: m0 (the lane select of the resolving wave's v_writelane block, inline asm) is used by that block only
+    m0 = [l for l in out.stdout.splitlines() if l.startswith("k_fps_m0")]
+    assert len(m0) == 1 and " foreign=0 " in m0[0] + " " and m0[0].endswith("detached=0") and " loads=3 " in m0[0], m0      # one block per points-per-thread instantiation
     assert out.returncode == 0, out.stdout[-2000:]

@@ -122,6 +122,21 @@ def main():
             if src == "k_wino43.hip" and "Li64ELi64" in name and (r["scratch_reloads_between_output_stores"] or r["vmcnt0_inside_plane_loop"]):
                 bad += 1
 
+    # k_fps.hip: the resolving wave keeps a round's samples in lanes through v_writelane with the lane select in m0, written in inline asm.
+    # m0 is a reserved register: the compiler does not track the clobber, so nothing else in the kernels may use it -- every m0 in the
+    # file's assembly must be one of the asm block's own instructions, and the s_mov that loads it must sit right in front of its users.
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + file_flags("k_fps.hip") + ["-o", out, os.path.join(CS, "k_fps.hip")], check=True, stderr=subprocess.DEVNULL)
+        lines = [l.split(";")[0].strip() for l in open(out).read().splitlines()]
+    lines = [l for l in lines if l and not l.startswith((".", "//"))]
+    m0 = [(i, l) for i, l in enumerate(lines) if re.search(r"\bm0\b", l)]
+    foreign = [l for _, l in m0 if not re.match(r"(s_mov_b32 m0, s\d+|v_writelane_b32 v\d+, s\d+, m0)$", l)]
+    loads = [i for i, l in m0 if l.startswith("s_mov_b32 m0")]
+    detached = [i for i in loads if not (lines[i + 1] == "s_nop 0" and all(lines[i + 2 + k].startswith("v_writelane_b32") and lines[i + 2 + k].endswith(", m0") for k in range(5)))]
+    print("k_fps_m0 uses=%d loads=%d foreign=%d detached=%d" % (len(m0), len(loads), len(foreign), len(detached)))
+    if foreign or detached or len(m0) != 6 * len(loads) or not loads:
+        bad += 1
     return 1 if bad else 0
 
 
