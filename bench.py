@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--cost-l0", default=None, choices=["collapsed", "direct"], help="bx_params.cost_l0_form")
     ap.add_argument("--inflight-sweep", default="1,2,4,8,16", help="pairs in flight of the throughput-vs-latency sweep after the timed region ('' = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--one-call", action="store_true", help="early-exit workloads: bx_register_pair (every launch of every scale enqueued, device-side skip) instead of the two-call form with the exit decision on the host")
     ap.add_argument("--e2e-pairs", type=int, default=96, help="pairs of the file-driven end-to-end measurement per RNG mode (0 = skip; N = 1 only); 96 = the step count of the hot-path measurement it is compared with (round 4 ran 24: fill and drain of 16 pairs in flight were a third of that run)")
     ap.add_argument("--num-fps", type=int, default=5000)
     ap.add_argument("--latency-tiles", type=int, default=2, help="keypoint tiles of the latency-form measurement (0/1 = skip it)")
@@ -278,6 +279,69 @@ def main():
             harvest(step)
         return lat, recs
 
+    def run_two_calls(n_steps, depth=C, ctxs=ctxs):
+        """Early-exit configurations: every pair as bx_register_pair_begin -> (host reads the exit decision) -> bx_register_pair_finish,
+        the way the reference takes the decision (models/BUFFERX.py:424-457), so that a pair that leaves at scale 0 never enqueues the
+        launches of the later scales.  Pairs differ in length now, so the contexts are served as they come free (an event poll), not
+        round-robin.  Same records as run(): global pair id of step s on rank r = r + world * s."""
+        lat, recs = [], []
+        free = list(range(depth))[::-1]
+        busy = {}            # context -> [phase, event a, event of the phase's end, gid]
+        nxt = done = 0
+        while done < n_steps:
+            moved = False
+            for c in list(busy):
+                ph, a, e, gid = busy[c]
+                if not e.query():
+                    continue
+                moved = True
+                th = time.perf_counter()
+                if ph == 1:
+                    with torch.cuda.stream(streams[c]):
+                        ctxs[c].register_pair_finish_async(int(flags[c][0]), results[c])
+                        b = torch.cuda.Event(enable_timing=True)
+                        b.record(streams[c])
+                    busy[c] = [2, a, b, gid]
+                else:
+                    lat.append(a.elapsed_time(e))
+                    r = results[c]
+                    if r.status != 0:
+                        raise RuntimeError("pair %d: bx_result.status = 0x%x" % (gid, r.status))
+                    if lib.forms_of_result(r) != forms:
+                        raise RuntimeError("pair %d ran in %s, configured %s" % (gid, lib.forms_of_result(r), forms))
+                    pose = np.array(r.pose, np.float64).reshape(4, 4)
+                    if cfg.test.pose_refine is True:
+                        pose = pose.astype(np.float32)
+                    recs.append(D.pack_record(gid, pose, r.num_inliers, r.num_mutual, r.num_inlier_ind, r.scales_used, lat[-1], r.ransac_iters))
+                    del busy[c]
+                    free.append(c)
+                    done += 1
+                host_s[0] += time.perf_counter() - th
+            while free and nxt < n_steps:
+                moved = True
+                c = free.pop()
+                gid = rank + world * nxt
+                dp = dpairs[gid % len(dpairs)]
+                th = time.perf_counter()
+                with torch.cuda.stream(streams[c]):
+                    a = torch.cuda.Event(enable_timing=True)
+                    e = torch.cuda.Event(enable_timing=True)
+                    a.record(streams[c])
+                    ctxs[c].register_pair_begin_async(dp["src"], dp["tgt"], dp["aligned"], dp["perm_src"], dp["perm_tgt"], dp["seed"], flags[c])
+                    e.record(streams[c])
+                busy[c] = [1, a, e, gid]
+                nxt += 1
+                host_s[0] += time.perf_counter() - th
+            if not moved:
+                time.sleep(2e-5)
+        order = np.argsort([int(r[0]) for r in recs], kind="stable")     # completion order -> pair order (what run() returns)
+        return [lat[i] for i in order], [recs[i] for i in order]
+
+    two_calls = bool(cfg.match.get("enable_early_exit", False)) and S > 1 and not args.one_call
+    flags = [cx.new_exit_flag() for cx in ctxs]
+    run_1 = run
+    if two_calls:
+        run = run_two_calls
     host_s = [0.0]       # host seconds spent enqueueing (the ~170 launches of a pair) and harvesting (record packing), waits excluded
     run(C)               # every context once (first-use costs: code objects, function attributes), before the W warm-up steps
     torch.cuda.synchronize()
@@ -334,8 +398,8 @@ def main():
         cfg_t = copy.deepcopy(cfg)
         cfg_t.test.keypoint_tiles = args.latency_tiles
         ctx_t = lib.Context(cfg_t, max_points=max(60000, max(max(len(p['src']), len(p['tgt'])) for p in pairs)), device=local, packed_weights=pw)
-        run(2, depth=1, ctxs=[ctx_t])
-        lat1t, rec1t = run(n1, depth=1, ctxs=[ctx_t])
+        run_1(2, depth=1, ctxs=[ctx_t])       # (the latency form has no two-call entry)
+        lat1t, rec1t = run_1(n1, depth=1, ctxs=[ctx_t])
         tiles_same = bool(all(np.array_equal(a[:22], b[:22]) for a, b in zip(rec1, rec1t)))
         ctx_t.close()
     # Kernel-quality pass: the same workload, ONE pair in flight, hipEvents around every stage on the kernels' own
@@ -503,7 +567,7 @@ def main():
                        # service time of ONE pair alone, throughput form / latency form (keypoint_tiles)
                        "p50_ms_per_pair": round(float(np.median(lat1)), 3),
                        "p50_ms_per_pair_latency_form": None if lat1t is None else round(float(np.median(lat1t)), 3),
-                       "pairs_in_flight_per_gpu": C, "arithmetic_forms": forms, "distinct_pairs": len(pairs), "parallelism": "pair-sharded x%d, one all-gather of %d B float64 records" % (world, 8 * D.RECORD),
+                       "pairs_in_flight_per_gpu": C, "pair_call": ("bx_register_pair_begin + _finish: the early-exit decision on the host, contexts served as they come free" if two_calls else "bx_register_pair"), "arithmetic_forms": forms, "distinct_pairs": len(pairs), "parallelism": "pair-sharded x%d, one all-gather of %d B float64 records" % (world, 8 * D.RECORD),
                        "weights": "seeded random (reference snapshot layout)", "mean_points_per_cloud": nmean,
                        "workload_generator": "synth.make_pair v2 (round 2+: shared=True noise-free partial-overlap fragments; round 1 used "
                                              "independently sampled jittered fragments = --workload 3dmatch-noisy; rates of the two are not comparable)"},

@@ -903,11 +903,18 @@ struct LaneScope {   // section of a pair that takes its turn on the lane
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ whole pair
-int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, const float* tgt, int32_t n_tgt, int32_t aligned_z,
-                     const int32_t* perm_src, const int32_t* perm_tgt, uint64_t seed, bx_result* result)
+}  // extern "C"
+
+// phase 0: the whole pair (bx_register_pair).  phase 1: up to and including the exit test of scale 0 -- every scale when no early exit can
+// follow -- and the copy of the decision to the host (bx_register_pair_begin).  phase 2: the rest, the host knowing whether the pair
+// left (bx_register_pair_finish).  One body: the two-call form enqueues the very launches of the one-call form, minus those a pair that
+// left would only have returned from.
+static int register_pair_impl(bx_ctx* c, void* stream, const float* src, int32_t n_src, const float* tgt, int32_t n_tgt, int32_t aligned_z,
+                              const int32_t* perm_src, const int32_t* perm_tgt, uint64_t seed, bx_result* result, int phase, bool exited,
+                              int32_t* exited_host)
 {
     BX_ENTER(c, true);
-    if (!src || !tgt || !perm_src || !perm_tgt || !result) { bx_set_error("bx_register_pair: null argument"); return BX_ERR_ARG; }
+    if (!src || !tgt || !perm_src || !perm_tgt || (!result && phase != 1)) { bx_set_error("bx_register_pair: null argument"); return BX_ERR_ARG; }
     const bx_params& p = c->p;
     if (n_src < 1 || n_tgt < 1 || n_src > p.max_points || n_tgt > p.max_points) {
         bx_set_error("bx_register_pair: cloud sizes %d/%d outside [1, max_points=%d]", n_src, n_tgt, p.max_points);
@@ -918,12 +925,9 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
     const int KM = K > NK ? K : NK;
     PairState* st = c->state;
     c->skip = nullptr;
-    hipLaunchKernelGGL(state_reset_kernel, dim3(1), dim3(64), 0, s, st, c->err_flag);
-
-    // (1) keypoints: ONE furthest-point sampling per cloud; FPS(nk) is a prefix of FPS(K) (SURVEY.md §8a row 2).
-    // Latency form (params.keypoint_tiles > 1): the run is cut into tiles of keypoints on the context's own stream; tile 0 ends
-    // where the radius estimation has its keypoints, and the descriptor work of a tile runs on the caller's stream while the next
-    // tile is still being sampled (a descriptor depends on its own keypoint only).
+    const bool early = p.enable_early_exit != 0;
+    if (phase != 0 && p.keypoint_tiles > 1) { bx_set_error("bx_register_pair_begin / _finish: throughput form only (keypoint_tiles <= 1)"); return BX_ERR_STATE; }
+    int ransac_calls = phase == 2 ? c->pend.ransac_calls : 0;
     const float* clouds[2] = {src, tgt};
     const int ns[2] = {n_src, n_tgt};
     const int32_t* perms[2] = {perm_src, perm_tgt};
@@ -933,6 +937,13 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
     const bool tiled = T > 1;                       // FPS in several launches on the context's own stream
     const bool multi = p.keypoint_tiles > 1;        // source / target / matching chains on the context's streams (also when K <= nk
                                                     // leaves nothing to tile: the reference's default num_fps = 1500 < 2000)
+    if (phase != 2) {
+    hipLaunchKernelGGL(state_reset_kernel, dim3(1), dim3(64), 0, s, st, c->err_flag);
+
+    // (1) keypoints: ONE furthest-point sampling per cloud; FPS(nk) is a prefix of FPS(K) (SURVEY.md §8a row 2).
+    // Latency form (params.keypoint_tiles > 1): the run is cut into tiles of keypoints on the context's own stream; tile 0 ends
+    // where the radius estimation has its keypoints, and the descriptor work of a tile runs on the caller's stream while the next
+    // tile is still being sampled (a descriptor depends on its own keypoint only).
     if (multi && c->cap_on) { bx_set_error("bx_register_pair: bx_set_capture needs keypoint_tiles <= 1"); return BX_ERR_STATE; }
     hipStream_t fs = tiled ? c->aux_stream : s;
     if (tiled) {
@@ -944,8 +955,10 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
         if (tiled) BX_HIP(hipEventRecord(c->ev_tile[t], fs));
     }
     if (tiled) BX_HIP(hipStreamWaitEvent(s, c->ev_tile[0], 0));
+    }   // phase != 2
 
     LaneScope lane_main(c, s, 1);
+    if (phase != 2) {
     // (2) radius estimation histogram: the LARGER cloud and its keypoints (models/BUFFERX.py:654-665), once per pair
     const int big = n_src > n_tgt ? 0 : 1;
     const float* rpts = clouds[big];
@@ -961,9 +974,9 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
     // sets in one batch of six launches; the per-scale permutation is applied on the fly
     { ProfScope ps(c, s, 1); if ((rc = bxk_radius_bisect_all(c, s, (int64_t)ns[big], NK, p.search_radius_thresholds, S, st->des_r)) != BX_OK) return rc; }
     // (with the early exit on, only scale 0's two grids: the later scales' are built behind the exit test and skipped with the pair)
-    const bool early = p.enable_early_exit != 0;
     c->skip = nullptr;
     { ProfScope ps(c, s, 13); if ((rc = bxk_ball_grids(c, s, clouds, ns, perms, 2, st->des_r, S, p.search_radius_thresholds, 0, early ? 1 : S)) != BX_OK) return rc; }
+    }   // phase != 2
 
     // descriptors of keypoints [k0, k0 + kn) of one (scale, cloud): neighbour gather -> patch features -> Cylindrical_Net
     // Latency form: the target cloud's chain runs on the context's second stream with its own scratch, so that the tail of one
@@ -1017,7 +1030,7 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
     // tile by tile: candidate tables of the tile (all sets, one launch), then its descriptors -- of every scale when no early exit
     // can skip the later ones, else of scale 0 only (the later scales then run over all keypoints behind the exit test)
     c->skip = nullptr;
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < T && phase != 2; ++t) {
         const int k0 = tb[t], kn = (t == T - 1 ? K : tb[t + 1]) - k0;
         if (tiled && t > 0) BX_HIP(hipStreamWaitEvent(s, c->ev_tile[t], 0));
         { ProfScope ps(c, s, 13); if ((rc = bxk_ball_rows(c, s, c->kpts, 2, S, k0, kn, 0, early ? 1 : S)) != BX_OK) return rc; }
@@ -1032,9 +1045,9 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
     hipStream_t s_caller = s;
     const bool split_match = multi && !early;
     if (!split_match) { if ((rc = tgt_join()) != BX_OK) return rc; }
-    int ransac_calls = 0;
     if (split_match) s = c->match_stream;
-    for (int i = 0; i < S; ++i) {
+    // (second call: scale 0 is done; a pair that left has nothing more to describe)
+    for (int i = phase == 2 ? (early ? (exited ? S : 1) : S) : 0; i < S; ++i) {
         if (split_match) {
             BX_HIP(hipStreamWaitEvent(s, c->ev_desc[0][i], 0));
             BX_HIP(hipStreamWaitEvent(s, c->ev_desc[1][i], 0));
@@ -1100,8 +1113,18 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
             if (rc != BX_OK) return rc;
             ++ransac_calls;
             hipLaunchKernelGGL(early_exit_kernel, dim3(1), dim3(64), 0, s, st, p.early_exit_min_inliers);
+            if (phase == 1 && S > 1) break;      // the host decides about the later scales
         }
     }
+    if (phase == 1) {
+        // the decision, stream-ordered (0 when nothing can be skipped: the second call then only finishes the pair)
+        if (early && S > 1) BX_HIP(hipMemcpyAsync(exited_host, &st->done, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        else *exited_host = 0;
+        BX_LAUNCH_CHECK();
+        c->pend = {true, src, tgt, n_src, n_tgt, aligned_z, perm_src, perm_tgt, seed, ransac_calls};
+        return BX_OK;
+    }
+    c->pend.active = false;
     if (split_match) {
         BX_HIP(hipEventRecord(c->ev_match_done, s));
         s = s_caller;
@@ -1109,7 +1132,7 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
         if ((rc = tgt_join()) != BX_OK) return rc;
     }
     // final pose estimation unless the early exit was taken (models/BUFFERX.py:449-457)
-    { ProfScope ps(c, s, 9);
+    if (!(phase == 2 && early && exited)) { ProfScope ps(c, s, 9);
     if (p.pose_estimator == 1) rc = bxk_kiss(c, s, c->ss_cat, c->tt_cat, c->inlier_ind, &st->C, S * K, nullptr, nullptr, early ? &st->done : nullptr);
     else rc = bxk_ransac(c, s, c->ss_cat, c->tt_cat, c->inlier_ind, &st->C, S * K, bx_mix64(seed, 0x5AC0000ULL + ransac_calls), nullptr, nullptr,
                          early ? &st->done : nullptr);
@@ -1125,6 +1148,28 @@ int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, c
     BX_LAUNCH_CHECK();
     BX_HIP(hipMemcpyAsync(result, c->result_dev, sizeof(bx_result), hipMemcpyDeviceToHost, s));
     return BX_OK;
+}
+
+extern "C" {
+
+int bx_register_pair(bx_ctx* c, void* stream, const float* src, int32_t n_src, const float* tgt, int32_t n_tgt, int32_t aligned_z,
+                     const int32_t* perm_src, const int32_t* perm_tgt, uint64_t seed, bx_result* result)
+{
+    return register_pair_impl(c, stream, src, n_src, tgt, n_tgt, aligned_z, perm_src, perm_tgt, seed, result, 0, false, nullptr);
+}
+
+int bx_register_pair_begin(bx_ctx* c, void* stream, const float* src, int32_t n_src, const float* tgt, int32_t n_tgt, int32_t aligned_z,
+                           const int32_t* perm_src, const int32_t* perm_tgt, uint64_t seed, int32_t* exited_host)
+{
+    if (!exited_host) { bx_set_error("bx_register_pair_begin: null argument"); return BX_ERR_ARG; }
+    return register_pair_impl(c, stream, src, n_src, tgt, n_tgt, aligned_z, perm_src, perm_tgt, seed, nullptr, 1, false, exited_host);
+}
+
+int bx_register_pair_finish(bx_ctx* c, void* stream, int32_t exited, bx_result* result)
+{
+    if (!c || !c->pend.active) { bx_set_error("bx_register_pair_finish: no pending bx_register_pair_begin on this context"); return BX_ERR_STATE; }
+    const bx_ctx::PendingPair a = c->pend;
+    return register_pair_impl(c, stream, a.src, a.n_src, a.tgt, a.n_tgt, a.aligned_z, a.perm_src, a.perm_tgt, a.seed, result, 2, exited != 0, nullptr);
 }
 
 }  // extern "C"

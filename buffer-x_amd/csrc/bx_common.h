@@ -193,6 +193,15 @@ struct bx_ctx {
     int conv_persist, conv_cap_override, n_cu;
     int desc_batch;                     // 1 (default): both clouds of a scale in one Cylindrical_Net stack (bx_api.hip::desc_stack_pair); hook BX_DESC_BATCH
     int rad_slices;                     // measurement hook BX_RAD_SLICES: point slices of radius_hist_kernel (0 = the default, 16)
+    // bx_register_pair_begin / _finish: the arguments of the pending pair (pointers remembered, not copied) and what the first call consumed
+    struct PendingPair {
+        bool active;
+        const float *src, *tgt;
+        int32_t n_src, n_tgt, aligned_z;
+        const int32_t *perm_src, *perm_tgt;
+        uint64_t seed;
+        int ransac_calls;
+    } pend;
     double *d_cost_wp, *d_cost_wq;      // collapsed CostNet layer 0 (k_cost.hip): binary64 weights of the P / Q convolutions
     int cost_direct;                    // bx_params.cost_l0_form == direct: layer 0 as the fp32 MFMA convolution of the implicit volume (cost_l1_kernel)
     int32_t* conv_ctr;                  // [2 * BX_NDESC] {next group ticket, departed workgroups} of the 32x32x2 kernels' group walk

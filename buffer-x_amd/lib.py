@@ -53,6 +53,7 @@ class BxCapture(C.Structure):
 
 
 EXPORTS = ["bx_create", "bx_destroy", "bx_last_error", "bx_load_weights", "bx_workspace_bytes", "bx_register_pair",
+           "bx_register_pair_begin", "bx_register_pair_finish",
            "bx_set_capture", "bx_keypoint_tile_bounds",
            "bx_profile_enable", "bx_profile_read", "bx_debug_read",
            "bx_fps", "bx_radius", "bx_permute", "bx_ball_group", "bx_patch_features", "bx_ball_group_counted", "bx_patch_features_counted",
@@ -518,6 +519,41 @@ class Context:
                                        C.c_int32(tgt.shape[0]), C.c_int32(int(aligned_z)), self._p(perm_src), self._p(perm_tgt),
                                        C.c_uint64(seed & (2**64 - 1)), C.byref(res)), "bx_register_pair")
         self._keep = [src, tgt, perm_src, perm_tgt, res]
+        return res
+
+    # the same in two calls, the early-exit decision taken on the host (include/bufferx.h: bx_register_pair_begin / _finish)
+    def new_exit_flag(self):
+        """pinned int32[1] the first call's asynchronous copy lands in (1 = the pair left at scale 0)"""
+        return self.torch.zeros(1, dtype=self.torch.int32).pin_memory()
+
+    def register_pair_begin_async(self, src, tgt, aligned_z, perm_src, perm_tgt, seed, flag):
+        """Enqueue a pair up to the exit test of scale 0 (every scale when no early exit can follow) on the current stream; `flag`
+        (new_exit_flag()) holds the decision once the stream has passed this call.  Follow with register_pair_finish_async."""
+        t = self.torch
+        src, tgt = self._dev(src, t.float32), self._dev(tgt, t.float32)
+        perm_src, perm_tgt = self._dev(perm_src, t.int32), self._dev(perm_tgt, t.int32)
+        _chk(self.lib.bx_register_pair_begin(self.handle, self._stream(), self._p(src), C.c_int32(src.shape[0]), self._p(tgt),
+                                             C.c_int32(tgt.shape[0]), C.c_int32(int(aligned_z)), self._p(perm_src), self._p(perm_tgt),
+                                             C.c_uint64(seed & (2**64 - 1)), C.c_void_p(flag.data_ptr())), "bx_register_pair_begin")
+        self._keep = [src, tgt, perm_src, perm_tgt, flag]
+        return flag
+
+    def register_pair_finish_async(self, exited, result=None):
+        """Enqueue the rest of the pending pair: the later scales unless `exited`, the final pose estimation, the refinement."""
+        res = result if result is not None else self.new_result()
+        _chk(self.lib.bx_register_pair_finish(self.handle, self._stream(), C.c_int32(int(bool(exited))), C.byref(res)), "bx_register_pair_finish")
+        self._keep = list(getattr(self, "_keep", [])) + [res]
+        return res
+
+    def register_pair_two_calls(self, src, tgt, aligned_z, perm_src, perm_tgt, seed):
+        """begin -> synchronise -> finish -> synchronise (the reference's own control flow, models/BUFFERX.py:424-457)"""
+        flag = self.register_pair_begin_async(src, tgt, aligned_z, perm_src, perm_tgt, seed, self.new_exit_flag())
+        st = self.torch.cuda.current_stream(self.device)
+        st.synchronize()
+        res = self.register_pair_finish_async(int(flag[0]))
+        st.synchronize()
+        if res.status != 0:
+            raise BxError(f"device-side failure bits 0x{res.status:x}")
         return res
 
     def register_pair(self, src, tgt, aligned_z, perm_src, perm_tgt, seed):

@@ -159,6 +159,26 @@ int bx_register_pair(bx_ctx *ctx, void *stream, const float *src, int32_t n_src,
                      int32_t aligned_z, const int32_t *perm_src, const int32_t *perm_tgt, uint64_t seed,
                      bx_result *result);
 
+/* ---- the same in two calls, with the early-exit decision taken on the HOST (models/BUFFERX.py:424-457: the reference tests
+ * `should_exit` on the host after scale 0 and breaks out of its scale loop).  bx_register_pair enqueues every launch of every scale
+ * and lets the kernels of the later scales return on a device flag: right for one pair alone (no host round trip), but with many
+ * pairs in flight the ~100 empty launches of a pair that left -- a third of them asking for a whole CU's LDS per workgroup -- still
+ * queue behind the other pairs' kernels: 2 % of the throughput of an early-exit configuration (BASELINE configs[4] geometry:
+ * 89.4 -> 91.3 pairs/s, profiles/r06_overlap.txt), and a pair that left holds its context until they have drained.
+ *   bx_register_pair_begin : everything up to and including the exit test of scale 0 (ALL scales when the early exit is off or
+ *                            num_scales == 1), then an asynchronous copy of the decision to *exited_host (HOST int32, pinned memory
+ *                            recommended: 1 = the pair left at scale 0).  The input pointers are remembered, not copied: they must
+ *                            stay valid until bx_register_pair_finish has been enqueued.
+ *   bx_register_pair_finish: called once the stream has passed the copy (event / stream synchronisation by the caller) with the
+ *                            value read: enqueues the later scales unless `exited`, the final pose estimation, the refinement and
+ *                            the result copy.  Same kernels in the same order as bx_register_pair on a pair that takes the same
+ *                            way: results are bit-identical (tests/test_gpu_pair.py).  Throughput form only (keypoint_tiles <= 1);
+ *                            BX_ERR_STATE without a pending begin.                                                              */
+int bx_register_pair_begin(bx_ctx *ctx, void *stream, const float *src, int32_t n_src, const float *tgt, int32_t n_tgt,
+                           int32_t aligned_z, const int32_t *perm_src, const int32_t *perm_tgt, uint64_t seed,
+                           int32_t *exited_host);
+int bx_register_pair_finish(bx_ctx *ctx, void *stream, int32_t exited, bx_result *result);
+
 /* ---- capture of intermediates (parity tests at sizes the CPU oracle cannot run end to end) ----------------------------------
  * While a capture is set, bx_register_pair copies (stream-ordered, device to device) the intermediates of ONE scale into
  * caller-owned device buffers; every pointer is nullable.  The per-cloud transients (permuted cloud, patches, voxel features,

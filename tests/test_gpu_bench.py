@@ -61,6 +61,22 @@ def test_world2_records_equal_world1(tmp_path):
     assert "e2e_pairs_per_s" not in j2
 
 
+def test_early_exit_workload_two_calls_equal_one_call(tmp_path):
+    """The early-exit workload (tiers) runs its pairs as bx_register_pair_begin / _finish with the exit decision on the host and the
+    contexts served as they come free; `--one-call` is bx_register_pair round-robin.  Same pairs, same records (pose, counts, scales
+    used), pair order restored; both exits and non-exits occur."""
+    ra, rb = str(tmp_path / "two.npy"), str(tmp_path / "one.npy")
+    small = ["--workload", "tiers", "--num-fps", "512", "--ppp", "128", "--distinct", "6", "--inflight", "3", "--warmup", "1", "--no-cpu-baseline",
+             "--e2e-pairs", "0", "--latency-tiles", "0", "--inflight-sweep", "", "--steps", "12"]
+    ja = _run([sys.executable, "bench.py", "--dump-records", ra] + small, {})
+    jb = _run([sys.executable, "bench.py", "--one-call", "--dump-records", rb] + small, {})
+    a, b = np.load(ra), np.load(rb)
+    keep = [i for i in range(24) if i != 22]
+    assert a.shape == b.shape == (12, 24) and np.array_equal(a[:, keep], b[:, keep]) and list(a[:, 0]) == list(range(12))
+    assert ja["config"]["pair_call"].startswith("bx_register_pair_begin") and jb["config"]["pair_call"] == "bx_register_pair"
+    assert ja["work"]["early_exit_taken"] == jb["work"]["early_exit_taken"] and ja["registered_ok"] == jb["registered_ok"]
+
+
 def test_world8_on_one_gpu_equals_world1(tmp_path):
     """De-risking the 8-GPU run without an 8-GPU box (round 4): `python bench.py --gpus 8` at the REAL headline configuration (K = 5000,
     P = 1024, 3 scales), eight ranks x four pairs in flight all on the ONE MI355X of the test box (gloo collectives): 32 contexts and HIP

@@ -97,6 +97,43 @@ def test_pair_matches_oracle_and_golden(bx, packed, oracle, golden_dir, name):
     assert rre < 1e-4 and rte < 1e-4
 
 
+@pytest.mark.parametrize("name", ["indoor_early", "indoor_3scale", "indoor_success", "outdoor_small", "baseline_cfg0"])
+def test_pair_in_two_calls_equals_one_call(bx, packed, oracle, name):
+    """bx_register_pair_begin / _finish (the early-exit decision taken on the host, as the reference takes it: models/BUFFERX.py:424-457)
+    against bx_register_pair on the same context: the exit taken at scale 0 (the later scales are never enqueued), armed but not taken,
+    switched off (the first call runs every scale), and a one-scale configuration -- every field of the result equal bit for bit, twice
+    in a row on the same context (no state of a pair that left survives into the next one), and the protocol errors."""
+    from bufferx_amd import lib
+    cfg, pair, seed = make_case(bx, name)
+    ctx = lib.Context(cfg, max_points=max(len(pair["src"]), len(pair["tgt"])), device=0, packed_weights=packed)
+    S = cfg.patch.num_scales
+    perm_s = np.stack([oracle.make_perm(len(pair["src"]), seed, 2 * i) for i in range(S)])
+    perm_t = np.stack([oracle.make_perm(len(pair["tgt"]), seed, 2 * i + 1) for i in range(S)])
+
+    def fields(r):
+        return (np.array(r.pose).tobytes(), r.num_inliers, r.num_mutual, r.num_inlier_ind, r.scales_used, r.ransac_iters, r.status,
+                tuple(r.des_r[i] for i in range(S)))
+    try:
+        with pytest.raises(lib.BxError):
+            ctx.register_pair_finish_async(0)          # nothing pending
+        one = fields(ctx.register_pair(pair["src"], pair["tgt"], pair["aligned_z"], perm_s, perm_t, seed))
+        for _ in range(2):
+            two = ctx.register_pair_two_calls(pair["src"], pair["tgt"], pair["aligned_z"], perm_s, perm_t, seed)
+            assert fields(two) == one
+        # the decision the host saw is the one the device took
+        import torch
+        flag = ctx.register_pair_begin_async(pair["src"], pair["tgt"], pair["aligned_z"], perm_s, perm_t, seed, ctx.new_exit_flag())
+        torch.cuda.current_stream(0).synchronize()
+        took = bool(cfg.match.get("enable_early_exit", False)) and S > 1 and name == "indoor_early"
+        assert int(flag[0]) == int(took)
+        res = ctx.register_pair_finish_async(int(flag[0]))
+        torch.cuda.current_stream(0).synchronize()
+        assert fields(res) == one and res.scales_used == (1 if took else S)
+        assert fields(ctx.register_pair(pair["src"], pair["tgt"], pair["aligned_z"], perm_s, perm_t, seed)) == one
+    finally:
+        ctx.close()
+
+
 def test_pair_larger_config_success(bx, packed, oracle):
     """K=1024, P=256, 2 scales on a 12k-point noisy partial-overlap pair: registration must succeed and agree
     with the oracle bit for bit."""
